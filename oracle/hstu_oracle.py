@@ -1,0 +1,562 @@
+"""CPU oracle for the HSTU hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  Nothing under ``generative_recommenders_amd/``
+imports it: the product path is the HIP library and fails loudly without it.
+
+Every function is a plain-numpy restatement (per-user loops, never visiting
+padded positions) of the algorithm of one reference function; the reference
+file:line it follows is cited in the docstring (paths relative to
+``/root/reference/generative_recommenders``).
+
+Pinning: the reference tree holds no golden vectors for this path
+(SURVEY.md §8c).  The oracle is pinned against outputs of the reference's own
+PyTorch path run in the build container -- ``tests/golden/make_golden.py``
+imports ``/root/reference`` (with a 3-op fbgemm shim) and writes
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every oracle
+function against those files.  The three ``fbgemm_gpu`` ops used by the
+reference (jagged_to_padded_dense / dense_to_jagged /
+asynchronous_complete_cumsum; fbgemm_gpu>=1.1.0 per requirements.txt:2, not
+vendored, not installed) are restated here from their published semantics and
+are pinned only indirectly, through the reference call sites that consume them.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# jagged / integer helpers (bit-exact domain)
+# --------------------------------------------------------------------------
+
+
+def complete_cumsum(lengths: np.ndarray) -> np.ndarray:
+    """[0, inclusive_scan(lengths)], dtype preserved.
+
+    Follows ops/cpp/complete_cumsum.cu:7-47 and the fbgemm op
+    ``asynchronous_complete_cumsum`` used at modules/stu.py:97.
+    """
+    lengths = np.asarray(lengths)
+    out = np.zeros(lengths.shape[0] + 1, dtype=lengths.dtype)
+    np.cumsum(lengths, out=out[1:])
+    return out
+
+
+def jagged_to_padded_dense(
+    values: np.ndarray, offsets: np.ndarray, max_len: int, padding_value: float = 0.0
+) -> np.ndarray:
+    """(sum L, D) -> (B, max_len, D); rows beyond max_len are dropped.
+
+    fbgemm ``jagged_to_padded_dense`` as consumed at
+    ops/pytorch/pt_hstu_attention.py:97-125.
+    """
+    B = offsets.shape[0] - 1
+    D = values.shape[1]
+    out = np.full((B, max_len, D), padding_value, dtype=values.dtype)
+    for b in range(B):
+        s, e = int(offsets[b]), int(offsets[b + 1])
+        n = min(e - s, max_len)
+        out[b, :n] = values[s : s + n]
+    return out
+
+
+def dense_to_jagged(dense: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+    """(B, N, D) -> (sum L, D), keeping the first L_b rows of each user.
+
+    fbgemm ``dense_to_jagged`` as consumed at
+    ops/pytorch/pt_hstu_attention.py:167-171.
+    """
+    B = offsets.shape[0] - 1
+    total = int(offsets[-1])
+    out = np.zeros((total, dense.shape[2]), dtype=dense.dtype)
+    for b in range(B):
+        s, e = int(offsets[b]), int(offsets[b + 1])
+        n = min(e - s, dense.shape[1])
+        out[s : s + n] = dense[b, :n]
+    return out
+
+
+def _dense_offsets(n_rows: int, max_len: int) -> np.ndarray:
+    B = n_rows // max_len
+    return (max_len * np.arange(B + 1)).astype(np.int64)
+
+
+def concat_2D_jagged(
+    values_left: np.ndarray,
+    values_right: np.ndarray,
+    max_len_left: Optional[int] = None,
+    max_len_right: Optional[int] = None,
+    offsets_left: Optional[np.ndarray] = None,
+    offsets_right: Optional[np.ndarray] = None,
+    n_prefix_from_right: int = 0,
+) -> np.ndarray:
+    """Per-user row concat [left_b ; right_b]; a side without offsets is dense
+    with ``max_len_*`` rows per user.
+
+    Follows ops/pytorch/pt_jagged_tensors.py:31-117 (and, for
+    ``n_prefix_from_right`` > 0, pytorch_hstu_concat_l2_embeddings :208-246:
+    the first ``n`` rows of the right side go in front of the left side).
+    """
+    if offsets_left is None:
+        offsets_left = _dense_offsets(values_left.shape[0], max_len_left)
+    if offsets_right is None:
+        offsets_right = _dense_offsets(values_right.shape[0], max_len_right)
+    B = offsets_left.shape[0] - 1
+    pieces = []
+    for b in range(B):
+        l = values_left[int(offsets_left[b]) : int(offsets_left[b + 1])]
+        r = values_right[int(offsets_right[b]) : int(offsets_right[b + 1])]
+        n = n_prefix_from_right
+        pieces += [r[:n], l, r[n:]]
+    return np.concatenate(pieces, axis=0) if pieces else values_left[:0]
+
+
+def split_2D_jagged(
+    values: np.ndarray,
+    max_len_left: Optional[int] = None,
+    max_len_right: Optional[int] = None,
+    offsets_left: Optional[np.ndarray] = None,
+    offsets_right: Optional[np.ndarray] = None,
+    n_prefix_to_right: int = 0,
+) -> Tuple[np.ndarray, np.ndarray]:
+    """Inverse of :func:`concat_2D_jagged`.
+
+    Follows ops/pytorch/pt_jagged_tensors.py:120-205 (prefix variant:
+    pytorch_hstu_split_l2_embeddings :176-205).
+    """
+    if offsets_left is None:
+        B = offsets_right.shape[0] - 1
+        offsets_left = (max_len_left * np.arange(B + 1)).astype(np.int64)
+    if offsets_right is None:
+        B = offsets_left.shape[0] - 1
+        offsets_right = (max_len_right * np.arange(B + 1)).astype(np.int64)
+    B = offsets_left.shape[0] - 1
+    lefts, rights = [], []
+    pos = 0
+    for b in range(B):
+        ll = int(offsets_left[b + 1] - offsets_left[b])
+        lr = int(offsets_right[b + 1] - offsets_right[b])
+        n = n_prefix_to_right
+        seg = values[pos : pos + ll + lr]
+        rights.append(seg[:n])
+        lefts.append(seg[n : n + ll])
+        rights.append(seg[n + ll :])
+        pos += ll + lr
+    left = np.concatenate(lefts, axis=0) if lefts else values[:0]
+    right = np.concatenate(rights, axis=0) if rights else values[:0]
+    return left, right
+
+
+def expand_1d_jagged_to_dense(values: np.ndarray, offsets: np.ndarray, max_len: int) -> np.ndarray:
+    """1-D jagged -> (B, max_len); pads with the user's LAST value (0 if empty).
+
+    Follows ops/cpp/expand_1d_jagged_to_dense.cpp:28-52.
+    """
+    B = offsets.shape[0] - 1
+    out = np.zeros((B, max_len), dtype=values.dtype)
+    for b in range(B):
+        s, e = int(offsets[b]), int(offsets[b + 1])
+        n = e - s
+        if n == 0:
+            continue
+        m = min(n, max_len)
+        out[b, :m] = values[s : s + m]
+        out[b, m:] = values[e - 1]
+    return out
+
+
+def concat_1d_jagged_jagged(
+    lengths_left: np.ndarray, values_left: np.ndarray, lengths_right: np.ndarray, values_right: np.ndarray
+) -> np.ndarray:
+    """Per-user concat of two 1-D jagged value arrays.
+
+    Follows ops/cpp/concat_1d_jagged_jagged.cu:33-62.
+    """
+    ol = complete_cumsum(np.asarray(lengths_left, dtype=np.int64))
+    orr = complete_cumsum(np.asarray(lengths_right, dtype=np.int64))
+    pieces = []
+    for b in range(len(lengths_left)):
+        pieces += [values_left[ol[b] : ol[b + 1]], values_right[orr[b] : orr[b + 1]]]
+    return np.concatenate(pieces) if pieces else values_left[:0]
+
+
+# --------------------------------------------------------------------------
+# attention mask (integer domain)
+# --------------------------------------------------------------------------
+
+
+def valid_attn_mask(
+    n: int,
+    seq_len: int,
+    num_targets: Optional[int] = None,
+    max_attn_len: int = 0,
+    contextual_seq_len: int = 0,
+    min_full_attn_seq_len: int = 0,
+) -> np.ndarray:
+    """Boolean (n, n) mask of one user, rows = queries, cols = keys.
+
+    Restates ops/pytorch/pt_hstu_attention.py:32-84 (causal branch) for a single
+    user of length ``seq_len``; ``n`` may be the padded N or just ``seq_len``.
+    """
+    pos = np.arange(n, dtype=np.int64)
+    ids = pos.copy()
+    max_id = int(seq_len)
+    if contextual_seq_len > 0:
+        ids = np.maximum(ids - contextual_seq_len + 1, 0)
+        max_id = max_id - contextual_seq_len + 1
+    if num_targets is not None:
+        max_id = max_id - int(num_targets)
+        ids = np.minimum(ids, max_id)
+    row = ids[:, None]
+    col = ids[None, :]
+    dist = row - col
+    valid = (pos[:, None] == pos[None, :]) | (dist > 0)
+    if max_attn_len > 0:
+        in_window = dist <= max_attn_len
+        if min_full_attn_seq_len > 0:
+            in_window = in_window | (row >= max_id - min_full_attn_seq_len)
+        valid = valid & in_window
+    if contextual_seq_len > 0:
+        valid = valid | ((row == 0) & (col < max_id))
+    return valid
+
+
+def _silu(x: np.ndarray) -> np.ndarray:
+    return x / (1.0 + np.exp(-x))
+
+
+def _sigmoid(x: np.ndarray) -> np.ndarray:
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+# --------------------------------------------------------------------------
+# ops-path attention: forward, backward, delta-q
+# --------------------------------------------------------------------------
+
+
+def hstu_mha_fwd(
+    max_seq_len: int,
+    alpha: float,
+    q: np.ndarray,
+    k: np.ndarray,
+    v: np.ndarray,
+    seq_offsets: np.ndarray,
+    num_targets: Optional[np.ndarray] = None,
+    max_attn_len: int = 0,
+    contextual_seq_len: int = 0,
+    min_full_attn_seq_len: int = 0,
+    dtype=np.float64,
+) -> np.ndarray:
+    """O = ((silu(alpha Q K^T) / N) * M) V per (user, head), jagged in/out.
+
+    Restates pytorch_hstu_mha, ops/pytorch/pt_hstu_attention.py:129-171
+    (padded positions contribute nothing, so they are never visited).
+    q,k: (sum L, H, dqk); v: (sum L, H, dv) -> (sum L, H, dv).
+    """
+    q = q.astype(dtype)
+    k = k.astype(dtype)
+    v = v.astype(dtype)
+    B = seq_offsets.shape[0] - 1
+    out = np.zeros((q.shape[0], q.shape[1], v.shape[2]), dtype=dtype)
+    for b in range(B):
+        s, e = int(seq_offsets[b]), int(seq_offsets[b + 1])
+        L = min(e - s, max_seq_len)
+        if L == 0:
+            continue
+        t = None if num_targets is None else int(num_targets[b])
+        M = valid_attn_mask(L, e - s, t, max_attn_len, contextual_seq_len, min_full_attn_seq_len)
+        qb, kb, vb = q[s : s + L], k[s : s + L], v[s : s + L]
+        S = alpha * np.einsum("ihd,jhd->hij", qb, kb)
+        P = _silu(S) / max_seq_len * M[None]
+        out[s : s + L] = np.einsum("hij,jhd->ihd", P, vb)
+    return out
+
+
+def hstu_mha_bwd(
+    max_seq_len: int,
+    alpha: float,
+    dout: np.ndarray,
+    q: np.ndarray,
+    k: np.ndarray,
+    v: np.ndarray,
+    seq_offsets: np.ndarray,
+    num_targets: Optional[np.ndarray] = None,
+    max_attn_len: int = 0,
+    contextual_seq_len: int = 0,
+    min_full_attn_seq_len: int = 0,
+    dtype=np.float64,
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Hand-derived backward of :func:`hstu_mha_fwd`:
+
+        dV = P^T dO ; dP = dO V^T ; dS = dP * M / N * sig(S) (1 + S (1 - sig(S)))
+        dQ = alpha dS K ; dK = alpha dS^T Q
+
+    Cross-checks: ops/triton/triton_hstu_attention.py:968-1006,1222 and
+    ops/cpp/hstu_attention/mainloop_bwd_sm80.h:886-944.
+    """
+    q = q.astype(dtype)
+    k = k.astype(dtype)
+    v = v.astype(dtype)
+    dout = dout.astype(dtype)
+    dq = np.zeros_like(q)
+    dk = np.zeros_like(k)
+    dv = np.zeros_like(v)
+    B = seq_offsets.shape[0] - 1
+    for b in range(B):
+        s, e = int(seq_offsets[b]), int(seq_offsets[b + 1])
+        L = min(e - s, max_seq_len)
+        if L == 0:
+            continue
+        t = None if num_targets is None else int(num_targets[b])
+        M = valid_attn_mask(L, e - s, t, max_attn_len, contextual_seq_len, min_full_attn_seq_len)
+        qb, kb, vb, dob = q[s : s + L], k[s : s + L], v[s : s + L], dout[s : s + L]
+        S = alpha * np.einsum("ihd,jhd->hij", qb, kb)
+        sig = _sigmoid(S)
+        P = S * sig / max_seq_len * M[None]
+        dv[s : s + L] = np.einsum("hij,ihd->jhd", P, dob)
+        dP = np.einsum("ihd,jhd->hij", dob, vb)
+        dS = dP * M[None] / max_seq_len * sig * (1.0 + S * (1.0 - sig))
+        dq[s : s + L] = alpha * np.einsum("hij,jhd->ihd", dS, kb)
+        dk[s : s + L] = alpha * np.einsum("hij,ihd->jhd", dS, qb)
+    return dq, dk, dv
+
+
+def delta_hstu_mha_fwd(
+    max_seq_len: int,
+    alpha: float,
+    delta_q: np.ndarray,
+    k: np.ndarray,
+    v: np.ndarray,
+    seq_offsets: np.ndarray,
+    num_targets: Optional[np.ndarray] = None,
+    max_attn_len: int = 0,
+    contextual_seq_len: int = 0,
+    dtype=np.float64,
+) -> np.ndarray:
+    """Attention of the last ``delta`` rows of each user against its full K/V.
+
+    Restates pytorch_cached_hstu_mha, ops/pytorch/pt_hstu_attention.py:174-235.
+    delta_q: (B*delta, H, dqk) dense per user -> (B*delta, H, dv).
+    """
+    B = seq_offsets.shape[0] - 1
+    delta = delta_q.shape[0] // B
+    delta_q = delta_q.astype(dtype)
+    k = k.astype(dtype)
+    v = v.astype(dtype)
+    out = np.zeros((delta_q.shape[0], delta_q.shape[1], v.shape[2]), dtype=dtype)
+    for b in range(B):
+        s, e = int(seq_offsets[b]), int(seq_offsets[b + 1])
+        L = e - s
+        t = None if num_targets is None else int(num_targets[b])
+        M = valid_attn_mask(L, L, t, max_attn_len, contextual_seq_len, 0)[L - delta :]
+        qb = delta_q[b * delta : (b + 1) * delta]
+        kb, vb = k[s:e], v[s:e]
+        S = alpha * np.einsum("ihd,jhd->hij", qb, kb)
+        P = _silu(S) / max_seq_len * M[None]
+        out[b * delta : (b + 1) * delta] = np.einsum("hij,jhd->ihd", P, vb)
+    return out
+
+
+# --------------------------------------------------------------------------
+# research-path attention with relative position / bucketed-time bias
+# --------------------------------------------------------------------------
+
+
+def rel_time_buckets(ts_row: np.ndarray, n: int) -> np.ndarray:
+    """bucket[i, j] = clamp(floor(log(max(|ext[i+1] - ext[j]|, 1)) / 0.301), 0, 128)
+    with ext = concat(ts[0..n-1], ts[n-1]).
+
+    Restates research/modeling/sequential/hstu.py:128-139 (bucketization fn
+    :610-612).  Returns int64 (n, n).
+    """
+    ts_row = np.asarray(ts_row[:n], dtype=np.int64)
+    ext = np.concatenate([ts_row, ts_row[n - 1 : n]])
+    diff = ext[1:, None] - ext[None, :-1]
+    val = np.log(np.maximum(np.abs(diff), 1).astype(np.float32)) / np.float32(0.301)
+    return np.clip(val.astype(np.int64), 0, 128)
+
+
+def rel_bias_attention_fwd(
+    n: int,
+    q: np.ndarray,
+    k: np.ndarray,
+    v: np.ndarray,
+    seq_offsets: np.ndarray,
+    timestamps: Optional[np.ndarray],
+    pos_w: np.ndarray,
+    ts_w: Optional[np.ndarray],
+    dtype=np.float64,
+) -> np.ndarray:
+    """Research-path attention: P = silu(q.k + pos_w[n-1+j-i] + ts_w[bkt]) / n * tril.
+
+    Restates _hstu_attention_maybe_from_cache + RelativeBucketedTimeAndPositionBasedBias,
+    research/modeling/sequential/hstu.py:150-223, 87-144.
+    q,k: (sum L, H, dqk), v: (sum L, H, dv), timestamps: (B, n) int64.
+    """
+    q = q.astype(dtype)
+    k = k.astype(dtype)
+    v = v.astype(dtype)
+    B = seq_offsets.shape[0] - 1
+    out = np.zeros((q.shape[0], q.shape[1], v.shape[2]), dtype=dtype)
+    for b in range(B):
+        s, e = int(seq_offsets[b]), int(seq_offsets[b + 1])
+        L = min(e - s, n)
+        if L == 0:
+            continue
+        i = np.arange(L)
+        bias = pos_w.astype(dtype)[(n - 1) + i[None, :] - i[:, None]]
+        if ts_w is not None:
+            bias = bias + ts_w.astype(dtype)[rel_time_buckets(timestamps[b], n)[:L, :L]]
+        S = np.einsum("ihd,jhd->hij", q[s : s + L], k[s : s + L]) + bias[None]
+        P = _silu(S) / n * (i[:, None] >= i[None, :])[None]
+        out[s : s + L] = np.einsum("hij,jhd->ihd", P, v[s : s + L])
+    return out
+
+
+def rel_bias_attention_bwd(
+    n: int,
+    dout: np.ndarray,
+    q: np.ndarray,
+    k: np.ndarray,
+    v: np.ndarray,
+    seq_offsets: np.ndarray,
+    timestamps: Optional[np.ndarray],
+    pos_w: np.ndarray,
+    ts_w: Optional[np.ndarray],
+    dtype=np.float64,
+):
+    """Backward of :func:`rel_bias_attention_fwd`; also returns d pos_w, d ts_w
+    (scatter-adds of dS over heads and users)."""
+    q = q.astype(dtype)
+    k = k.astype(dtype)
+    v = v.astype(dtype)
+    dout = dout.astype(dtype)
+    dq, dk, dv = np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)
+    dpos = np.zeros(pos_w.shape, dtype=dtype)
+    dts = None if ts_w is None else np.zeros(ts_w.shape, dtype=dtype)
+    B = seq_offsets.shape[0] - 1
+    for b in range(B):
+        s, e = int(seq_offsets[b]), int(seq_offsets[b + 1])
+        L = min(e - s, n)
+        if L == 0:
+            continue
+        i = np.arange(L)
+        pidx = (n - 1) + i[None, :] - i[:, None]
+        bias = pos_w.astype(dtype)[pidx]
+        if ts_w is not None:
+            bkt = rel_time_buckets(timestamps[b], n)[:L, :L]
+            bias = bias + ts_w.astype(dtype)[bkt]
+        tril = (i[:, None] >= i[None, :])[None]
+        S = np.einsum("ihd,jhd->hij", q[s : s + L], k[s : s + L]) + bias[None]
+        sig = _sigmoid(S)
+        P = S * sig / n * tril
+        dv[s : s + L] = np.einsum("hij,ihd->jhd", P, dout[s : s + L])
+        dP = np.einsum("ihd,jhd->hij", dout[s : s + L], v[s : s + L])
+        dS = dP * tril / n * sig * (1.0 + S * (1.0 - sig))
+        dq[s : s + L] = np.einsum("hij,jhd->ihd", dS, k[s : s + L])
+        dk[s : s + L] = np.einsum("hij,ihd->jhd", dS, q[s : s + L])
+        dSh = dS.sum(axis=0)
+        np.add.at(dpos, pidx, dSh)
+        if ts_w is not None:
+            np.add.at(dts, bkt, dSh)
+    return dq, dk, dv, dpos, dts
+
+
+# --------------------------------------------------------------------------
+# norms and the projections around attention
+# --------------------------------------------------------------------------
+
+
+def layer_norm_fwd(x, weight, bias, eps, dtype=np.float64):
+    """Row LayerNorm with affine, math in ``dtype``.  ops/pytorch/pt_layer_norm.py:24-38."""
+    x = x.astype(dtype)
+    mean = x.mean(axis=1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    return (x - mean) * rstd * weight.astype(dtype) + bias.astype(dtype)
+
+
+def layer_norm_bwd(dy, x, weight, eps, dtype=np.float64):
+    """dx, dweight, dbias of :func:`layer_norm_fwd`."""
+    x = x.astype(dtype)
+    dy = dy.astype(dtype)
+    w = weight.astype(dtype)
+    mean = x.mean(axis=1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * rstd
+    g = dy * w
+    dx = rstd * (g - g.mean(axis=1, keepdims=True) - xhat * (g * xhat).mean(axis=1, keepdims=True))
+    return dx, (dy * xhat).sum(axis=0), dy.sum(axis=0)
+
+
+def group_norm_rows(x, weight, bias, eps, num_heads, linear_dim, dtype=np.float64):
+    """Per-row, per-head normalisation with one (weight, bias) scalar per head.
+
+    F.group_norm on (-1, H, linear_dim) with num_groups=H as used at
+    ops/pytorch/pt_hstu_linear.py:43-50."""
+    x = x.astype(dtype).reshape(-1, num_heads, linear_dim)
+    mean = x.mean(axis=2, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=2, keepdims=True)
+    y = (x - mean) / np.sqrt(var + eps)
+    y = y * weight.astype(dtype)[None, :, None] + bias.astype(dtype)[None, :, None]
+    return y.reshape(-1, num_heads * linear_dim)
+
+
+def hstu_compute_uqvk(x, norm_weight, norm_bias, norm_eps, num_heads, attn_dim, hidden_dim,
+                      uvqk_weight, uvqk_bias, dtype=np.float64):
+    """LN_affine(x) @ W + b, split [u, v, q, k], silu on u only.
+
+    Restates ops/hstu_compute.py:50-89."""
+    nx = layer_norm_fwd(x, norm_weight, norm_bias, norm_eps, dtype)
+    uvqk = nx @ uvqk_weight.astype(dtype) + uvqk_bias.astype(dtype)
+    hv, ha = hidden_dim * num_heads, attn_dim * num_heads
+    u = _silu(uvqk[:, :hv])
+    v = uvqk[:, hv : 2 * hv].reshape(-1, num_heads, hidden_dim)
+    q = uvqk[:, 2 * hv : 2 * hv + ha].reshape(-1, num_heads, attn_dim)
+    k = uvqk[:, 2 * hv + ha :].reshape(-1, num_heads, attn_dim)
+    return u, q, k, v
+
+
+def norm_mul(attn, u, weight, bias, eps, concat_ux, group_norm, num_heads, linear_dim, dtype=np.float64):
+    """y = u * LN_or_GN(attn), optionally concat [u, attn, y] (dropout off).
+
+    Restates pytorch_norm_mul_dropout, ops/pytorch/pt_hstu_linear.py:23-65."""
+    attn = attn.astype(dtype)
+    u = u.astype(dtype)
+    if group_norm:
+        n = group_norm_rows(attn, weight, bias, eps, num_heads, linear_dim, dtype)
+    else:
+        n = layer_norm_fwd(attn, weight, bias, eps, dtype)
+    y = u * n
+    if concat_ux:
+        y = np.concatenate([u, attn, y], axis=1)
+    return y
+
+
+def hstu_compute_output(attn, u, x, norm_weight, norm_bias, norm_eps, output_weight,
+                        num_heads, linear_dim, concat_ux, group_norm, dtype=np.float64):
+    """x + norm_mul(attn, u) @ W_o.  Restates ops/pytorch/pt_hstu_linear.py:68-99."""
+    y = norm_mul(attn, u, norm_weight, norm_bias, norm_eps, concat_ux, group_norm, num_heads, linear_dim, dtype)
+    return x.astype(dtype) + y @ output_weight.astype(dtype)
+
+
+# --------------------------------------------------------------------------
+# synthetic length generators (measurement inputs)
+# --------------------------------------------------------------------------
+
+
+def generate_sparse_seq_len(rng: np.random.Generator, size: int, max_seq_len: int, sparsity: float) -> np.ndarray:
+    """Length distribution of common.py:173-201 (numpy RNG, so streams differ)."""
+    if sparsity == 0.0:
+        return np.zeros(size, dtype=np.int32)
+    if sparsity == 1.0:
+        return np.full(size, max_seq_len, dtype=np.int32)
+    if sparsity >= 0.5:
+        lo = int((2 * sparsity - 1.0) * max_seq_len)
+        return rng.integers(lo, max_seq_len, size=size, dtype=np.int32)
+    hi = int(2 * sparsity * max_seq_len)
+    return rng.integers(0, hi, size=size, dtype=np.int32)

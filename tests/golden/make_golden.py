@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Mint golden fixtures from the REFERENCE's own PyTorch path.
+
+Run in the build container only (needs /root/reference, which does not exist on
+the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports ``generative_recommenders`` from /root/reference unmodified, supplies
+the three absent ``fbgemm_gpu`` ops through ``_fbgemm_shim`` (pure-torch
+CompositeImplicitAutograd restatements), runs the HammerKernel.PYTORCH branch of
+each hot-path function on seeded CPU inputs drawn from the distributions of the
+reference's tests (ops/tests/hstu_attention_test.py:62-120) and stores inputs +
+outputs + gradients as small ``.npz`` files next to this script.  The committed
+``.npz`` files are what ``tests/`` reads; this script is committed so they can
+be regenerated.
+"""
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+
+import _fbgemm_shim  # noqa: F401  (registers torch.ops.fbgemm.*)
+
+from generative_recommenders.common import HammerKernel  # noqa: E402
+from generative_recommenders.ops.hstu_attention import delta_hstu_mha, hstu_mha  # noqa: E402
+from generative_recommenders.ops.hstu_compute import (  # noqa: E402
+    hstu_compute_output,
+    hstu_compute_uqvk,
+)
+from generative_recommenders.ops.jagged_tensors import (  # noqa: E402
+    concat_2D_jagged,
+    hstu_concat_l2_embeddings,
+    hstu_split_l2_embeddings,
+    split_2D_jagged,
+)
+from generative_recommenders.ops.layer_norm import layer_norm  # noqa: E402
+from generative_recommenders.modules.stu import STULayer, STULayerConfig, STUStack  # noqa: E402
+
+PT = HammerKernel.PYTORCH
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _lengths(gen, B, max_uih_len, max_targets, contextual, with_targets):
+    """lengths = randint(max_uih_len + 1) + num_targets + contextual
+    (ops/tests/hstu_attention_test.py:62-85)."""
+    uih = torch.randint(0, max_uih_len + 1, (B,), generator=gen)
+    if with_targets:
+        nt = torch.randint(1, max_targets + 1, (B,), generator=gen)
+    else:
+        nt = torch.zeros(B, dtype=torch.int64)
+    lengths = uih + nt + contextual
+    return lengths, nt
+
+
+def attention_cases():
+    gen = torch.Generator().manual_seed(20250629)
+    cases = []
+    cfgs = [
+        # B, H, max_uih, max_tgt, dqk, dv, targets, window, contextual, min_full
+        (4, 2, 40, 6, 16, 32, False, False, 0, 0),
+        (5, 2, 40, 6, 32, 16, True, False, 0, 0),
+        (4, 1, 50, 8, 16, 16, False, True, 0, 0),
+        (6, 2, 50, 8, 32, 32, True, True, 0, 0),
+        (4, 2, 40, 6, 16, 32, False, False, 5, 0),
+        (5, 3, 40, 6, 16, 16, True, True, 5, 0),
+        (4, 2, 60, 6, 16, 16, True, True, 0, 7),
+        (4, 2, 60, 6, 32, 16, True, True, 4, 9),
+        (3, 2, 48, 4, 64, 64, True, False, 0, 0),
+    ]
+    for ci, (B, H, mu, mt, dqk, dv, tg, win, ctx, mf) in enumerate(cfgs):
+        lengths, nt = _lengths(gen, B, mu, mt, ctx, tg)
+        if ci == 1:
+            lengths[0] = nt[0] + ctx  # zero-history user
+        N = int(lengths.max().item())
+        N = max(N, 1)
+        offsets = torch.zeros(B + 1, dtype=torch.int64)
+        offsets[1:] = torch.cumsum(lengths, 0)
+        Ltot = int(offsets[-1])
+        w = int(torch.randint(1, max(mu // 5, 2), (1,), generator=gen)) if win else 0
+        alpha = 1.0 / (dqk**0.5)
+        q = torch.empty(Ltot, H, dqk).uniform_(-0.1, 0.1, generator=gen).requires_grad_()
+        k = torch.empty(Ltot, H, dqk).uniform_(-0.1, 0.1, generator=gen).requires_grad_()
+        v = torch.empty(Ltot, H, dv).uniform_(-0.1, 0.1, generator=gen).requires_grad_()
+        dout = torch.randn(Ltot, H, dv, generator=gen) * 0.1
+        out = hstu_mha(
+            max_seq_len=N, alpha=alpha, q=q, k=k, v=v, seq_offsets=offsets, causal=True,
+            dropout_pr=0.0, training=False, num_targets=nt if tg else None, max_attn_len=w,
+            contextual_seq_len=ctx, min_full_attn_seq_len=mf, kernel=PT,
+        )
+        out.backward(dout)
+        cases.append(dict(
+            N=N, alpha=alpha, H=H, dqk=dqk, dv=dv, offsets=_np(offsets),
+            num_targets=_np(nt) if tg else None, max_attn_len=w, contextual=ctx, min_full=mf,
+            q=_np(q), k=_np(k), v=_np(v), dout=_np(dout), out=_np(out),
+            dq=_np(q.grad), dk=_np(k.grad), dv_=_np(v.grad),
+        ))
+    return cases
+
+
+def delta_cases():
+    gen = torch.Generator().manual_seed(77)
+    cases = []
+    for (B, H, mu, delta, dqk, dv, tg, win, ctx) in [
+        (4, 2, 40, 6, 16, 32, True, False, 0),
+        (3, 2, 50, 8, 32, 32, True, True, 4),
+        (4, 1, 30, 5, 16, 16, False, False, 0),
+    ]:
+        uih = torch.randint(0, mu + 1, (B,), generator=gen)
+        nt = torch.randint(1, delta + 1, (B,), generator=gen)
+        lengths = uih + delta + ctx
+        N = int(lengths.max())
+        offsets = torch.zeros(B + 1, dtype=torch.int64)
+        offsets[1:] = torch.cumsum(lengths, 0)
+        Ltot = int(offsets[-1])
+        w = int(torch.randint(1, max(mu // 5, 2), (1,), generator=gen)) if win else 0
+        alpha = 1.0 / (dqk**0.5)
+        dq_ = torch.empty(B * delta, H, dqk).uniform_(-0.1, 0.1, generator=gen)
+        k = torch.empty(Ltot, H, dqk).uniform_(-0.1, 0.1, generator=gen)
+        v = torch.empty(Ltot, H, dv).uniform_(-0.1, 0.1, generator=gen)
+        out = delta_hstu_mha(
+            max_seq_len=N, alpha=alpha, delta_q=dq_, k=k, v=v, seq_offsets=offsets,
+            num_targets=nt if tg else None, max_attn_len=w, contextual_seq_len=ctx, kernel=PT,
+        )
+        cases.append(dict(
+            N=N, alpha=alpha, delta=delta, offsets=_np(offsets), num_targets=_np(nt) if tg else None,
+            max_attn_len=w, contextual=ctx, delta_q=_np(dq_), k=_np(k), v=_np(v), out=_np(out),
+        ))
+    return cases
+
+
+def jagged_cases():
+    gen = torch.Generator().manual_seed(5)
+    cases = []
+    for (B, ma, mb, D, dense_a, dense_b) in [
+        (4, 20, 30, 13, False, False),
+        (5, 25, 10, 24, True, False),
+        (3, 20, 15, 10, False, True),
+        (6, 8, 8, 30, False, False),
+    ]:
+        la = torch.full((B,), ma) if dense_a else torch.randint(0, ma + 1, (B,), generator=gen)
+        lb = torch.full((B,), mb) if dense_b else torch.randint(0, mb + 1, (B,), generator=gen)
+        oa = torch.zeros(B + 1, dtype=torch.int64); oa[1:] = torch.cumsum(la, 0)
+        ob = torch.zeros(B + 1, dtype=torch.int64); ob[1:] = torch.cumsum(lb, 0)
+        va = torch.randn(int(oa[-1]), D, generator=gen)
+        vb = torch.randn(int(ob[-1]), D, generator=gen)
+        cat = concat_2D_jagged(
+            max_seq_len=ma + mb, values_left=va, values_right=vb, max_len_left=ma, max_len_right=mb,
+            offsets_left=None if dense_a else oa, offsets_right=None if dense_b else ob, kernel=PT,
+        )
+        sl, sr = split_2D_jagged(
+            max_seq_len=ma + mb, values=cat, max_len_left=ma if dense_a else None,
+            max_len_right=mb if dense_b else None, offsets_left=None if dense_a else oa,
+            offsets_right=None if dense_b else ob, kernel=PT,
+        )
+        cases.append(dict(ma=ma, mb=mb, dense_a=dense_a, dense_b=dense_b, oa=_np(oa), ob=_np(ob),
+                          va=_np(va), vb=_np(vb), cat=_np(cat), split_l=_np(sl), split_r=_np(sr)))
+    # l2-embedding prefix variants
+    B, mp, ml, D, ctx = 4, 12, 16, 8, 3
+    lp = torch.randint(0, mp + 1, (B,), generator=gen)
+    ll = torch.randint(ctx, ml + 1, (B,), generator=gen)
+    op = torch.zeros(B + 1, dtype=torch.int64); op[1:] = torch.cumsum(lp, 0)
+    ol = torch.zeros(B + 1, dtype=torch.int64); ol[1:] = torch.cumsum(ll, 0)
+    px = torch.randn(int(op[-1]), D, generator=gen)
+    lx = torch.randn(int(ol[-1]), D, generator=gen)
+    cat = hstu_concat_l2_embeddings(max_prefix_len=mp, prefix_x=px, prefix_offsets=op, max_l2_len=ml,
+                                    l2_x=lx, l2_offsets=ol, contextual_seq_len=ctx, kernel=PT)
+    sp, sl2 = hstu_split_l2_embeddings(max_seq_len=mp + ml, x=cat, prefix_offsets=op, l2_offsets=ol,
+                                       contextual_seq_len=ctx, kernel=PT)
+    l2case = dict(mp=mp, ml=ml, ctx=ctx, op=_np(op), ol=_np(ol), px=_np(px), lx=_np(lx),
+                  cat=_np(cat), split_p=_np(sp), split_l=_np(sl2))
+    return cases, l2case
+
+
+def compute_cases():
+    gen = torch.Generator().manual_seed(9)
+    out = {}
+    # layer norm
+    x = torch.randn(37, 48, generator=gen)
+    w = torch.randn(48, generator=gen); b = torch.randn(48, generator=gen)
+    out["ln"] = dict(x=_np(x), w=_np(w), b=_np(b), eps=1e-6, y=_np(layer_norm(x, w, b, 1e-6, kernel=PT)))
+    # uvqk
+    N, D, H, A, Hd = 29, 32, 2, 16, 24
+    x = torch.randn(N, D, generator=gen).requires_grad_()
+    nw = (1 + 0.1 * torch.randn(D, generator=gen)).requires_grad_()
+    nb = (0.1 * torch.randn(D, generator=gen)).requires_grad_()
+    W = (0.1 * torch.randn(D, 2 * H * (A + Hd), generator=gen)).requires_grad_()
+    beta = (0.1 * torch.randn(2 * H * (A + Hd), generator=gen)).requires_grad_()
+    u, q, k, v = hstu_compute_uqvk(x, nw, nb, 1e-6, H, A, Hd, W, beta, kernel=PT)
+    g = [torch.randn_like(t) for t in (u, q, k, v)]
+    (u * g[0]).sum().add((q * g[1]).sum()).add((k * g[2]).sum()).add((v * g[3]).sum()).backward()
+    out["uvqk"] = dict(x=_np(x), nw=_np(nw), nb=_np(nb), W=_np(W), beta=_np(beta), H=H, A=A, Hd=Hd,
+                       u=_np(u), q=_np(q), k=_np(k), v=_np(v), gu=_np(g[0]), gq=_np(g[1]), gk=_np(g[2]),
+                       gv=_np(g[3]), dx=_np(x.grad), dnw=_np(nw.grad), dnb=_np(nb.grad), dW=_np(W.grad),
+                       dbeta=_np(beta.grad))
+    # output op: LN / GN x concat
+    for name, gn, cat in [("out_ln", False, False), ("out_ln_cat", False, True), ("out_gn_cat", True, True)]:
+        N, H, Ld, D = 23, 2, 16, 24
+        attn = torch.randn(N, H * Ld, generator=gen).requires_grad_()
+        u = torch.randn(N, H * Ld, generator=gen).requires_grad_()
+        x = torch.randn(N, D, generator=gen).requires_grad_()
+        nshape = H if gn else H * Ld
+        nw = (1 + 0.1 * torch.randn(nshape, generator=gen)).requires_grad_()
+        nb = (0.1 * torch.randn(nshape, generator=gen)).requires_grad_()
+        Wo = (0.1 * torch.randn((3 if cat else 1) * H * Ld, D, generator=gen)).requires_grad_()
+        y = hstu_compute_output(attn=attn, u=u, x=x, norm_weight=nw, norm_bias=nb, norm_eps=1e-6,
+                                output_weight=Wo, num_heads=H, linear_dim=Ld, dropout_ratio=0.0,
+                                training=False, concat_ux=cat, group_norm=gn,
+                                recompute_y_in_backward=False, kernel=PT)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        out[name] = dict(attn=_np(attn), u=_np(u), x=_np(x), nw=_np(nw), nb=_np(nb), Wo=_np(Wo), H=H, Ld=Ld,
+                         gn=gn, cat=cat, y=_np(y), gy=_np(gy), dattn=_np(attn.grad), du=_np(u.grad),
+                         dx=_np(x.grad), dnw=_np(nw.grad), dnb=_np(nb.grad), dWo=_np(Wo.grad))
+    return out
+
+
+def stu_case():
+    torch.manual_seed(1234)
+    gen = torch.Generator().manual_seed(4321)
+    B, D, H, A, Hd, N = 4, 32, 2, 16, 24, 30
+    layers = []
+    for gn in (False, True):
+        cfg = STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=Hd, attention_dim=A,
+                             output_dropout_ratio=0.0, causal=True, target_aware=True, max_attn_len=None,
+                             attn_alpha=None, use_group_norm=gn, recompute_normed_x=True,
+                             recompute_uvqk=True, recompute_y=True, sort_by_length=True, contextual_seq_len=0)
+        layers.append(STULayer(cfg, is_inference=False))
+    stack = STUStack(layers, is_inference=False)
+    stack.set_hammer_kernel(PT)
+    for p in stack.parameters():  # make biases / norm params non-trivial
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn(p.shape, generator=gen))
+    nt = torch.randint(1, 4, (B,), generator=gen)
+    lengths = torch.randint(0, N - 4, (B,), generator=gen) + nt
+    offsets = torch.zeros(B + 1, dtype=torch.int64); offsets[1:] = torch.cumsum(lengths, 0)
+    x = torch.randn(int(offsets[-1]), D, generator=gen).requires_grad_()
+    y = stack(x=x, x_lengths=lengths, x_offsets=offsets, max_seq_len=N, num_targets=nt)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    d = dict(D=D, H=H, A=A, Hd=Hd, N=N, lengths=_np(lengths), offsets=_np(offsets), num_targets=_np(nt),
+             x=_np(x), y=_np(y), gy=_np(gy), dx=_np(x.grad))
+    for name, p in stack.named_parameters():
+        d["p:" + name] = _np(p)
+        d["g:" + name] = _np(p.grad)
+    return d
+
+
+def research_case():
+    """Research-path attention with relative position + bucketed time bias
+    (research/modeling/sequential/hstu.py:87-223)."""
+    from generative_recommenders.research.modeling.sequential.hstu import (
+        RelativeBucketedTimeAndPositionBasedBias,
+        _hstu_attention_maybe_from_cache,
+    )
+    gen = torch.Generator().manual_seed(31)
+    B, H, A, Ld, n = 4, 2, 16, 16, 24
+    lengths = torch.randint(1, n + 1, (B,), generator=gen)
+    lengths[0] = n
+    offsets = torch.zeros(B + 1, dtype=torch.int64); offsets[1:] = torch.cumsum(lengths, 0)
+    Lt = int(offsets[-1])
+    torch.manual_seed(3)
+    bias = RelativeBucketedTimeAndPositionBasedBias(
+        max_seq_len=n, num_buckets=128,
+        bucketization_fn=lambda x: (torch.log(torch.abs(x).clamp(min=1)) / 0.301).long())
+    ts = torch.sort(torch.randint(0, 10**8, (B, n), generator=gen), dim=1).values
+    q = (0.3 * torch.randn(Lt, H * A, generator=gen)).requires_grad_()
+    k = (0.3 * torch.randn(Lt, H * A, generator=gen)).requires_grad_()
+    v = (0.3 * torch.randn(Lt, H * Ld, generator=gen)).requires_grad_()
+    mask = 1.0 - torch.triu(torch.ones(n, n), diagonal=1)
+    out, _, _ = _hstu_attention_maybe_from_cache(
+        num_heads=H, attention_dim=A, linear_dim=Ld, q=q, k=k, v=v, cached_q=None, cached_k=None,
+        delta_x_offsets=None, x_offsets=offsets, all_timestamps=ts, invalid_attn_mask=mask,
+        rel_attn_bias=bias)
+    g = torch.randn_like(out)
+    out.backward(g)
+    return dict(n=n, H=H, A=A, Ld=Ld, offsets=_np(offsets), ts=_np(ts), q=_np(q), k=_np(k), v=_np(v),
+                pos_w=_np(bias._pos_w), ts_w=_np(bias._ts_w), out=_np(out), g=_np(g), dq=_np(q.grad),
+                dk=_np(k.grad), dv_=_np(v.grad), dpos_w=_np(bias._pos_w.grad), dts_w=_np(bias._ts_w.grad))
+
+
+def _save_cases(path, cases):
+    flat = {}
+    for i, c in enumerate(cases):
+        for key, val in c.items():
+            if val is None:
+                continue
+            flat[f"c{i}:{key}"] = np.asarray(val)
+    flat["n_cases"] = np.asarray(len(cases))
+    np.savez_compressed(path, **flat)
+
+
+def main():
+    torch.set_num_threads(1)
+    _save_cases(os.path.join(HERE, "attention.npz"), attention_cases())
+    _save_cases(os.path.join(HERE, "delta_attention.npz"), delta_cases())
+    jc, l2 = jagged_cases()
+    _save_cases(os.path.join(HERE, "jagged.npz"), jc)
+    _save_cases(os.path.join(HERE, "jagged_l2.npz"), [l2])
+    cc = compute_cases()
+    _save_cases(os.path.join(HERE, "compute.npz"), [dict(name=np.asarray(n), **c) for n, c in cc.items()])
+    _save_cases(os.path.join(HERE, "stu.npz"), [stu_case()])
+    _save_cases(os.path.join(HERE, "research_attention.npz"), [research_case()])
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

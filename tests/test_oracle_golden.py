@@ -1,0 +1,187 @@
+"""Pins the numpy oracle (oracle/hstu_oracle.py) to the golden vectors minted from
+the reference's own PyTorch path (tests/golden/make_golden.py).  CPU only."""
+
+import numpy as np
+import pytest
+
+from conftest import load_cases, scalar
+from oracle import hstu_oracle as O
+
+TOL = dict(rtol=2e-5, atol=2e-6)  # golden is fp32 torch; oracle runs fp64
+
+
+def _nt(c):
+    return c.get("num_targets")
+
+
+@pytest.mark.parametrize("idx", range(9))
+def test_attention_fwd_bwd_matches_reference(idx):
+    c = load_cases("attention.npz")[idx]
+    kw = dict(
+        num_targets=_nt(c), max_attn_len=int(c["max_attn_len"]), contextual_seq_len=int(c["contextual"]),
+        min_full_attn_seq_len=int(c["min_full"]),
+    )
+    N, alpha = int(c["N"]), float(c["alpha"])
+    out = O.hstu_mha_fwd(N, alpha, c["q"], c["k"], c["v"], c["offsets"], **kw)
+    np.testing.assert_allclose(out, c["out"], **TOL)
+    dq, dk, dv = O.hstu_mha_bwd(N, alpha, c["dout"], c["q"], c["k"], c["v"], c["offsets"], **kw)
+    np.testing.assert_allclose(dq, c["dq"], **TOL)
+    np.testing.assert_allclose(dk, c["dk"], **TOL)
+    np.testing.assert_allclose(dv, c["dv_"], **TOL)
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_delta_attention_matches_reference(idx):
+    c = load_cases("delta_attention.npz")[idx]
+    out = O.delta_hstu_mha_fwd(
+        int(c["N"]), float(c["alpha"]), c["delta_q"], c["k"], c["v"], c["offsets"], num_targets=_nt(c),
+        max_attn_len=int(c["max_attn_len"]), contextual_seq_len=int(c["contextual"]),
+    )
+    np.testing.assert_allclose(out, c["out"], **TOL)
+
+
+def test_delta_equals_tail_of_full():
+    """Metamorphic check of ops/tests/hstu_attention_test.py:356-486."""
+    rng = np.random.default_rng(0)
+    B, H, d, delta = 3, 2, 16, 4
+    lengths = rng.integers(delta, 30, size=B)
+    off = O.complete_cumsum(lengths.astype(np.int64))
+    N = int(lengths.max())
+    q = rng.uniform(-0.1, 0.1, (off[-1], H, d))
+    k = rng.uniform(-0.1, 0.1, (off[-1], H, d))
+    v = rng.uniform(-0.1, 0.1, (off[-1], H, d))
+    nt = rng.integers(1, delta + 1, size=B)
+    full = O.hstu_mha_fwd(N, 0.25, q, k, v, off, num_targets=nt)
+    dq = np.concatenate([q[off[b + 1] - delta : off[b + 1]] for b in range(B)])
+    dl = O.delta_hstu_mha_fwd(N, 0.25, dq, k, v, off, num_targets=nt)
+    tail = np.concatenate([full[off[b + 1] - delta : off[b + 1]] for b in range(B)])
+    np.testing.assert_allclose(dl, tail, rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_jagged_concat_split_bit_exact(idx):
+    c = load_cases("jagged.npz")[idx]
+    da, db = bool(c["dense_a"]), bool(c["dense_b"])
+    ma, mb = int(c["ma"]), int(c["mb"])
+    cat = O.concat_2D_jagged(c["va"], c["vb"], ma, mb, None if da else c["oa"], None if db else c["ob"])
+    assert np.array_equal(cat, c["cat"])
+    l, r = O.split_2D_jagged(c["cat"], ma if da else None, mb if db else None,
+                             None if da else c["oa"], None if db else c["ob"])
+    assert np.array_equal(l, c["split_l"]) and np.array_equal(r, c["split_r"])
+    assert np.array_equal(l, c["va"]) and np.array_equal(r, c["vb"])
+
+
+def test_jagged_l2_prefix_variants_bit_exact():
+    c = load_cases("jagged_l2.npz")[0]
+    ctx = int(c["ctx"])
+    cat = O.concat_2D_jagged(c["px"], c["lx"], None, None, c["op"], c["ol"], n_prefix_from_right=ctx)
+    assert np.array_equal(cat, c["cat"])
+    p, l = O.split_2D_jagged(c["cat"], None, None, c["op"], c["ol"], n_prefix_to_right=ctx)
+    assert np.array_equal(p, c["split_p"]) and np.array_equal(l, c["split_l"])
+
+
+def test_padded_dense_roundtrip_and_cumsum():
+    rng = np.random.default_rng(1)
+    lengths = rng.integers(0, 9, size=7).astype(np.int32)
+    off = O.complete_cumsum(lengths)
+    assert off.dtype == np.int32 and off[0] == 0 and off[-1] == lengths.sum()
+    vals = rng.standard_normal((off[-1], 5)).astype(np.float32)
+    dense = O.jagged_to_padded_dense(vals, off, 10)
+    assert np.array_equal(O.dense_to_jagged(dense, off), vals)
+    # truncation when max_len < L
+    dense2 = O.jagged_to_padded_dense(vals, off, 3)
+    for b in range(7):
+        n = min(lengths[b], 3)
+        assert np.array_equal(dense2[b, :n], vals[off[b] : off[b] + n])
+        assert not dense2[b, n:].any()
+
+
+def test_1d_jagged_helpers():
+    vals = np.array([1, 2, 3, 4, 5, 6], dtype=np.int64)
+    off = np.array([0, 2, 2, 6], dtype=np.int64)
+    d = O.expand_1d_jagged_to_dense(vals, off, 3)
+    assert d.tolist() == [[1, 2, 2], [0, 0, 0], [3, 4, 5]]
+    c = O.concat_1d_jagged_jagged(np.array([1, 0, 2]), np.array([7, 8, 9]), np.array([2, 1, 0]), np.array([1, 2, 3]))
+    assert c.tolist() == [7, 1, 2, 3, 8, 9]
+
+
+def _compute(name):
+    for c in load_cases("compute.npz"):
+        if str(c["name"]) == name:
+            return c
+    raise KeyError(name)
+
+
+def test_layer_norm_matches_reference():
+    c = _compute("ln")
+    y = O.layer_norm_fwd(c["x"], c["w"], c["b"], float(c["eps"]))
+    np.testing.assert_allclose(y, c["y"], rtol=2e-5, atol=2e-6)
+
+
+def test_uvqk_matches_reference():
+    c = _compute("uvqk")
+    u, q, k, v = O.hstu_compute_uqvk(c["x"], c["nw"], c["nb"], 1e-6, int(c["H"]), int(c["A"]), int(c["Hd"]),
+                                     c["W"], c["beta"])
+    for got, want in ((u, c["u"]), (q, c["q"]), (k, c["k"]), (v, c["v"])):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["out_ln", "out_ln_cat", "out_gn_cat"])
+def test_compute_output_matches_reference(name):
+    c = _compute(name)
+    y = O.hstu_compute_output(c["attn"], c["u"], c["x"], c["nw"], c["nb"], 1e-6, c["Wo"], int(c["H"]),
+                              int(c["Ld"]), bool(c["cat"]), bool(c["gn"]))
+    np.testing.assert_allclose(y, c["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_layer_norm_bwd_against_finite_difference():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((5, 12))
+    w = rng.standard_normal(12)
+    b = rng.standard_normal(12)
+    dy = rng.standard_normal((5, 12))
+    dx, dw, db = O.layer_norm_bwd(dy, x, w, 1e-6)
+    eps = 1e-6
+    num = np.zeros_like(x)
+    for i in range(5):
+        for j in range(12):
+            xp = x.copy(); xp[i, j] += eps
+            xm = x.copy(); xm[i, j] -= eps
+            num[i, j] = ((O.layer_norm_fwd(xp, w, b, 1e-6) - O.layer_norm_fwd(xm, w, b, 1e-6)) * dy).sum() / (2 * eps)
+    np.testing.assert_allclose(dx, num, rtol=1e-5, atol=1e-7)
+
+
+def test_research_rel_bias_attention_matches_reference():
+    c = load_cases("research_attention.npz")[0]
+    n, H = int(c["n"]), int(c["H"])
+    A, Ld = int(c["A"]), int(c["Ld"])
+    q = c["q"].reshape(-1, H, A)
+    k = c["k"].reshape(-1, H, A)
+    v = c["v"].reshape(-1, H, Ld)
+    out = O.rel_bias_attention_fwd(n, q, k, v, c["offsets"], c["ts"], c["pos_w"], c["ts_w"])
+    np.testing.assert_allclose(out.reshape(c["out"].shape), c["out"], rtol=2e-5, atol=2e-6)
+    g = c["g"].reshape(-1, H, Ld)
+    dq, dk, dv, dpos, dts = O.rel_bias_attention_bwd(n, g, q, k, v, c["offsets"], c["ts"], c["pos_w"], c["ts_w"])
+    np.testing.assert_allclose(dq.reshape(c["dq"].shape), c["dq"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dk.reshape(c["dk"].shape), c["dk"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dv.reshape(c["dv_"].shape), c["dv_"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dpos, c["dpos_w"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(dts, c["dts_w"], rtol=2e-4, atol=2e-6)
+
+
+def test_mask_zero_history_and_properties():
+    # zero-history user: only targets; each target sees itself only
+    m = O.valid_attn_mask(3, 3, num_targets=3)
+    assert np.array_equal(m, np.eye(3, dtype=bool))
+    # plain causal
+    m = O.valid_attn_mask(5, 5)
+    assert np.array_equal(m, np.tril(np.ones((5, 5), dtype=bool)))
+    # window of 2 without targets: row i sees cols [i-2, i]
+    m = O.valid_attn_mask(6, 6, max_attn_len=2)
+    for i in range(6):
+        for j in range(6):
+            assert m[i, j] == (0 <= i - j <= 2)
+    # contextual rows see the whole history but not targets
+    m = O.valid_attn_mask(8, 8, num_targets=2, contextual_seq_len=3)
+    assert m[0, :6].all() and not m[0, 6:].any()
+    assert m[7, :6].all() and m[7, 7] and not m[7, 6]
