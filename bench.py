@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""bench.py -- HSTU attention fwd+bwd throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path -- hstu attention forward + backward through the
+C ABI (libhstu_hip.so) -- over one batch of synthetic jagged user sequences that is already
+resident in HBM.  Metric shape M: N=200, H=4, dqk=dv=128 (d=512), bf16,
+8192 users per GPU; q, k, v are strided views of one fused (sum L, H, 3*128) buffer drawn
+uniform(-0.01, 0.01) with seed 1001 (as ops/benchmarks/hstu_attention_bench.py:194-233
+builds them); dout = randn.  Users shard across ranks (weak scaling: per-GPU work fixed);
+attention has no parameters, hence no collective in the timed region -- the ranks only
+meet at the barriers that bracket it.  The secondary "layer" section times 3 STU layers
+(D=512) fwd+bwd WITH the RCCL gradient all-reduce inside the step.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with the extra objects
+  roofline     -- dominant kernel (backward): algorithmic bytes / HIP-event kernel time vs 8 TB/s
+  cpu_baseline -- the padded-dense CPU port of the reference's PyTorch path on the host cores
+"""
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ~6.3 TB/s
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
+
+
+def make_lengths(workload, B, N, gen, device):
+    if workload == "M-full":
+        return torch.full((B,), N, dtype=torch.int64, device=device)
+    lo = int(0.9 * N)  # generate_sparse_seq_len(sparsity=0.95): randint(int(0.9 N), N)
+    return torch.randint(lo, N, (B,), generator=gen, device=device, dtype=torch.int64)
+
+
+def attention_section(args, rank, world, device):
+    from generative_recommenders_amd import data_parallel as dp
+    from generative_recommenders_amd.ops import _launch
+
+    N, H, d = args.max_seq_len, args.heads, args.head_dim
+    B = args.users_per_gpu
+    gen = torch.Generator(device=device).manual_seed(1001 + rank)
+    lengths = make_lengths(args.workload if args.workload != "M-targets" else "M-jag", B, N, gen, device)
+    off = dp.local_offsets(lengths)
+    L = int(off[-1].item())
+    dtype = torch.bfloat16
+    fused = torch.empty(L, H, 3 * d, device=device, dtype=dtype).uniform_(-0.01, 0.01, generator=gen)
+    q, k, v = torch.split(fused, [d, d, d], dim=-1)
+    dout = torch.randn(L, H, d, device=device, dtype=dtype, generator=gen)
+    nt = None
+    if args.workload == "M-targets":
+        nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
+    dfused = torch.empty_like(fused)
+    dq, dk, dv = torch.split(dfused, [d, d, d], dim=-1)
+    alpha = d**-0.5
+
+    def step():
+        out = _launch.attn_fwd(q, k, v, off, nt, N, alpha, 1.0 / N)
+        _launch.attn_bwd(dout, q, k, v, off, nt, N, alpha, 1.0 / N, dq=dq, dk=dk, dv=dv)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        out = _launch.attn_fwd(q, k, v, off, nt, N, alpha, 1.0 / N)
+        ev[i][1].record()
+        _launch.attn_bwd(dout, q, k, v, off, nt, N, alpha, 1.0 / N, dq=dq, dk=dk, dv=dv)
+        ev[i][2].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = dp.max_over_ranks(t1 - t0, device)
+    fwd_ms = statistics.mean(e[0].elapsed_time(e[1]) for e in ev)
+    bwd_ms = statistics.mean(e[1].elapsed_time(e[2]) for e in ev)
+    total_L = dp.sum_over_ranks(float(L), device)
+    es = 2
+    fwd_bytes = L * H * (2 * d + 2 * d) * es
+    bwd_bytes = L * H * (4 * d + 3 * d) * es
+    flops_user = lambda Lb: 4 * H * d * Lb * Lb + 3 * H * d * Lb * Lb  # fwd+bwd, causal-halved (bench :35-59)
+    flops = float(sum(flops_user(float(x)) for x in lengths.tolist())) if B <= 100000 else 0.0
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dfused.float()).all()
+    return dict(
+        elapsed=elapsed, users=B, rows=L, total_rows=total_L, fwd_ms=fwd_ms, bwd_ms=bwd_ms,
+        fwd_gbps=fwd_bytes / fwd_ms / 1e6, bwd_gbps=bwd_bytes / bwd_ms / 1e6,
+        both_gbps=(fwd_bytes + bwd_bytes) / (fwd_ms + bwd_ms) / 1e6, bwd_bytes=bwd_bytes, fwd_bytes=fwd_bytes,
+        tflops=flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
+    )
+
+
+def copy_bandwidth(device):
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def layer_section(args, rank, world, device):
+    """3 x STULayer (D=512, H=4, dqk=dv=128, group norm, target-aware) fwd+bwd + gradient
+    all-reduce, bf16 activations (DLRM-v3 HSTU config, dlrm_v3/configs.py:30-41)."""
+    from generative_recommenders_amd import data_parallel as dp
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig, STUStack
+
+    N, H, d, D = args.max_seq_len, args.heads, args.head_dim, args.heads * args.head_dim
+    B = args.layer_users_per_gpu
+    gen = torch.Generator(device=device).manual_seed(2002 + rank)
+    lengths = make_lengths("M-jag", B, N, gen, device)
+    off = dp.local_offsets(lengths)
+    L = int(off[-1].item())
+    torch.manual_seed(7)
+    stack = STUStack([STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=d, attention_dim=d,
+                                              output_dropout_ratio=0.0, use_group_norm=True)) for _ in range(3)])
+    stack = stack.to(device)
+    x = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen).requires_grad_()
+    gy = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen)
+    nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
+    reducer = dp.GradientAllReducer(stack.parameters())
+
+    def step():
+        for p in stack.parameters():
+            p.grad = None
+        x.grad = None
+        y = stack(x=x, x_lengths=lengths, x_offsets=off, max_seq_len=N, num_targets=nt)
+        y.backward(gy)
+        reducer.reduce()
+
+    for _ in range(3):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.layer_steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0, device)
+    nparams = sum(p.numel() for p in stack.parameters())
+    gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
+    return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,
+                user_seqs_per_s=world * B * args.layer_steps / elapsed, params=nparams,
+                allreduce_bytes=nparams * 4,
+                gemm_mfma_frac_if_all_time_were_gemm=gemm_flops * args.layer_steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS)
+
+
+def cpu_baseline(args):
+    """The reference's padded-dense PyTorch algorithm (ported: oracle/dense_torch.py) fwd+bwd on
+    the host cores, fp32, on a bounded sample of the same workload."""
+    from oracle.dense_torch import dense_hstu_mha
+
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    N, H, d = args.max_seq_len, args.heads, args.head_dim
+    B = args.cpu_users
+    gen = torch.Generator().manual_seed(1001)
+    lengths = make_lengths(args.workload if args.workload != "M-targets" else "M-jag", B, N, gen, "cpu")
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lengths, 0)
+    L = int(off[-1])
+    q = torch.empty(L, H, d).uniform_(-0.01, 0.01, generator=gen).requires_grad_()
+    k = torch.empty(L, H, d).uniform_(-0.01, 0.01, generator=gen).requires_grad_()
+    v = torch.empty(L, H, d).uniform_(-0.01, 0.01, generator=gen).requires_grad_()
+    do = torch.randn(L, H, d, generator=gen)
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        out = dense_hstu_mha(N, d**-0.5, q, k, v, off)
+        out.backward(do)
+        times.append(time.perf_counter() - t0)
+        q.grad = k.grad = v.grad = None
+    med = statistics.median(times[1:])
+    return dict(value=B / med, unit="user-seqs/s", cores=cores, kind="port",
+                sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of 3 after 1 warm-up "
+                       f"({med * 1e3:.0f} ms each); oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="M-full", choices=["M-full", "M-jag", "M-targets"])
+    ap.add_argument("--users-per-gpu", type=int, default=8192)
+    ap.add_argument("--max-seq-len", type=int, default=200)
+    ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--layer-users-per-gpu", type=int, default=1024)
+    ap.add_argument("--layer-steps", type=int, default=10)
+    ap.add_argument("--cpu-users", type=int, default=256)
+    ap.add_argument("--no-layer", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    from generative_recommenders_amd import _lib
+    from generative_recommenders_amd import data_parallel as dp
+
+    rank, local_rank, world = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HSTU ops are HIP kernels with no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    _lib.lib()
+
+    att = attention_section(args, rank, world, device)
+    value = world * att["users"] * args.steps / att["elapsed"]
+    res = {
+        "metric": "user-seqs/sec (fwd+bwd) HSTU attention L=200 d=512",
+        "value": value,
+        "unit": "user-seqs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": att["elapsed"] / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {args.users_per_gpu} users/GPU, L<= {args.max_seq_len}, H={args.heads}, "
+                        f"dqk=dv={args.head_dim}, q/k/v strided views of one fused buffer, attention fwd+bwd via C ABI",
+            "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "parallelism": f"dp{world} (no collective: attention has no parameters)",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "hstu_attn_bwd_kernel<bf16,128,128>",
+            "achieved": att["bwd_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att["bwd_gbps"] / HBM_PEAK_GBPS,
+            "traffic": None, "algorithmic_bytes_per_launch": att["bwd_bytes"], "avg_launch_ms": att["bwd_ms"],
+        },
+        "roofline_fwd": {
+            "bound": "hbm", "kernel": "hstu_attn_fwd_kernel<bf16,128,128>", "achieved": att["fwd_gbps"],
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att["fwd_gbps"] / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_launch": att["fwd_bytes"], "avg_launch_ms": att["fwd_ms"],
+        },
+        "roofline_fwd_bwd": {"achieved": att["both_gbps"], "unit": "GB/s", "frac": att["both_gbps"] / HBM_PEAK_GBPS,
+                             "tflops_causal_model": att["tflops"]},
+    }
+    if rank == 0:
+        try:
+            res["measured_copy_GBps"] = copy_bandwidth(device)
+        except Exception as e:  # pragma: no cover
+            res["measured_copy_GBps"] = f"error: {e}"
+    if not args.no_layer:
+        try:
+            res["layer"] = layer_section(args, rank, world, device)
+        except Exception as e:  # the headline number must survive a failure of the secondary section
+            res["layer"] = {"error": repr(e)[:300]}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        try:
+            res["cpu_baseline"] = cpu_baseline(args)
+        except Exception as e:  # pragma: no cover
+            res["cpu_baseline"] = {"error": repr(e)[:300]}
+    if rank == 0:
+        print(json.dumps(res))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""ctypes binding of libhstu_hip.so (C ABI declared in include/hstu_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing, stale or the
+wrong ABI version, importing the ops raises immediately (``HstuLibraryError``).
+PyTorch is used for device memory and streams only; tensors cross the boundary as
+raw device pointers + strides.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime our .so binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhstu_hip.so")
+ABI_VERSION = 1
+
+HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
+HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
+
+
+class HstuLibraryError(RuntimeError):
+    pass
+
+
+class HstuAttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
+        ("seq_offsets", C.c_void_p), ("num_targets", C.c_void_p),
+        ("q_row_stride", C.c_int64), ("q_head_stride", C.c_int64),
+        ("k_row_stride", C.c_int64), ("k_head_stride", C.c_int64),
+        ("v_row_stride", C.c_int64), ("v_head_stride", C.c_int64),
+        ("o_row_stride", C.c_int64), ("o_head_stride", C.c_int64),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("dqk", C.c_int32), ("dv", C.c_int32),
+        ("max_seq_len", C.c_int32), ("delta_q", C.c_int32),
+        ("alpha", C.c_float), ("scale", C.c_float),
+        ("max_attn_len", C.c_int32), ("contextual_seq_len", C.c_int32), ("min_full_attn_seq_len", C.c_int32),
+        ("dtype", C.c_int32), ("offsets_dtype", C.c_int32), ("targets_dtype", C.c_int32),
+    ]
+
+
+class HstuAttnBwdParams(C.Structure):
+    _fields_ = [
+        ("fwd", HstuAttnParams),
+        ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+        ("do_row_stride", C.c_int64), ("do_head_stride", C.c_int64),
+        ("dq_row_stride", C.c_int64), ("dq_head_stride", C.c_int64),
+        ("dk_row_stride", C.c_int64), ("dk_head_stride", C.c_int64),
+        ("dv_row_stride", C.c_int64), ("dv_head_stride", C.c_int64),
+        ("workspace", C.c_void_p), ("total_rows", C.c_int64),
+    ]
+
+
+_vp, _i32, _i64, _f32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_int
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); mirrors include/hstu_hip.h exactly (checked by tests/test_abi.py)
+SIGNATURES = {
+    "hstu_abi_version": (_int, []),
+    "hstu_last_error": (C.c_char_p, []),
+    "hstu_attn_fwd": (_int, [C.POINTER(HstuAttnParams), _vp]),
+    "hstu_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(HstuAttnBwdParams)]),
+    "hstu_attn_bwd": (_int, [C.POINTER(HstuAttnBwdParams), _vp]),
+    "hstu_complete_cumsum": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "hstu_concat_2d_jagged": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _int, _vp]),
+    "hstu_split_2d_jagged": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _int, _vp]),
+    "hstu_jagged_to_padded_dense": (_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _int, _vp]),
+    "hstu_dense_to_jagged": (_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _int, _vp]),
+    "hstu_expand_1d_jagged_to_dense": (_int, [_vp, _vp, _vp, _i32, _i32, _i32, _int, _vp]),
+    "hstu_concat_1d_jagged_jagged": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _int, _vp]),
+    "hstu_layer_norm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _int, _vp]),
+    "hstu_layer_norm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _int, _vp]),
+    "hstu_norm_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32]),
+    "hstu_norm_mul_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _int, _int, _int, _vp]),
+    "hstu_norm_mul_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _int, _int, _int, _vp]),
+    "hstu_silu_fwd": (_int, [_vp, _vp, _i64, _i32, _i64, _i64, _int, _vp]),
+    "hstu_silu_bwd": (_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _int, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libhstu_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", str(os.cpu_count() or 4)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise HstuLibraryError("building libhstu_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raise loudly if it is not usable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HstuLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C generative_recommenders_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback for the HSTU ops."
+        )
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HstuLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HstuLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.hstu_abi_version()
+    if got != ABI_VERSION:
+        raise HstuLibraryError(f"{LIB_PATH} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+    _lib = handle
+    return _lib
+
+
+def check(code: int) -> None:
+    """Turn a negative HSTU_E* return code into a RuntimeError carrying the library's message
+    (the reference surfaces TORCH_CHECK failures as RuntimeError too)."""
+    if code != 0:
+        msg = lib().hstu_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libhstu_hip error {code}: {msg}")
+
+
+def torch_dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return HSTU_DTYPE_BF16
+    if dtype == torch.float16:
+        return HSTU_DTYPE_F16
+    if dtype == torch.float32:
+        return HSTU_DTYPE_F32
+    raise RuntimeError(f"HSTU HIP ops support bf16 / fp16 / fp32 tensors, got {dtype}")
+
+
+def index_dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.int64:
+        return HSTU_INDEX_I64
+    if t.dtype == torch.int32:
+        return HSTU_INDEX_I32
+    raise RuntimeError(f"offsets / num_targets must be int32 or int64, got {t.dtype}")
+
+
+def current_stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must live on the GPU: the HSTU ops are HIP kernels with no CPU fallback "
+            f"(got device {t.device})"
+        )

@@ -1,0 +1,23 @@
+// Internal helpers shared by the translation units of libhstu_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/hstu_hip.h"
+
+namespace hstu {
+int set_error(int code, const char* fmt, ...);   // records the message, returns `code`
+int check_launch(const char* what);              // hipGetLastError() -> HSTU_OK | HSTU_ELAUNCH
+
+// per-dtype attention launchers (one translation unit each, so they compile in parallel)
+int launch_attn_fwd_bf16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_fwd_f16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_fwd_f32(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_bwd_bf16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_f16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_f32(const HstuAttnBwdParams& p, hipStream_t st);
+size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& p);
+int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len);
+
+inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }
+constexpr int kLdsBudget = 160 * 1024;
+}  // namespace hstu

@@ -1,0 +1,333 @@
+// HSTU attention backward for gfx950: one pass, dq/dk/dv from dout.
+//
+//   S = alpha Q K^T,  sg = sigmoid(S),  P = S sg scale M
+//   dV = P^T dO,  dP = dO V^T,  dS = dP M scale sg (1 + S (1 - sg))
+//   dQ = alpha dS K,  dK = alpha dS^T Q                       
+//
+// Replaces triton_hstu_attention_bwd (ops/triton/triton_hstu_attention.py:1849-1948,
+// kernels :899-1764) and hstu::hstu_mha_bwd (ops/cpp/hstu_attention/flash_api.cpp:111-141).
+//
+// Mapping.  One workgroup of 8 waves owns one (user, head, block of NW*32 keys), NW<=8.
+// The K/V rows of the block stay RESIDENT in LDS (row-major, swizzled); query/dO tiles
+// of 32 rows stream through one LDS stage (next tile prefetched into registers).  For
+// every query tile:
+//   phase 1  wave w < NW (owner of key tile w):
+//            S  = Q_i K_w^T, dP = dO_i V_w^T            (keys on the lane axis)
+//            P, dS element-wise in registers; C layout == B layout of the next MFMAs
+//            dV_w^T += dO_i^T P      dK_w^T += Q_i^T dS   (A through LDS transpose reads;
+//            accumulators live in registers for the whole kernel: no atomics)
+//            dS (already scaled by alpha) is published to LDS as [key][q]
+//   phase 2  wave d < DQK/32: dQ_i^T[32d..32d+32) = sum over key tiles K_w^T dS_w^T
+//            (a plain GEMM over all keys of the block: the cross-wave reduction of dQ
+//            happens in the MFMA accumulator instead of in memory)
+// When one block covers the user's whole sequence (the common case: L <= 32*NW) dQ is
+// written once, in the I/O dtype.  Longer sequences use several key blocks and add
+// their fp32 dQ partials into a zeroed workspace that a second tiny kernel converts
+// (the CUDA reference does this for every shape: flash_common.cpp:806-816).
+// q, k, v and dout are each read from HBM exactly once per (user, head) in the
+// single-block case; dq, dk, dv are written once.
+#pragma once
+#include "hstu_attn_fwd.cuh"
+
+namespace hstu {
+
+constexpr int kBwdThreads = 512;
+constexpr int kBwdWaves = 8;
+
+template <typename T, int DQK, int DV>
+struct BwdCfg {
+  static constexpr int EB = Elem<T>::kBytes;
+  static constexpr int EPU = 16 / EB;
+  static constexpr int UPR_K = DQK * EB / 16;
+  static constexpr int UPR_V = DV * EB / 16;
+  static constexpr int KT = 32 * DQK * EB;
+  static constexpr int VT = 32 * DV * EB;
+  static constexpr int PAIR = KT + VT;            // K+V tile, also Q+dO stage
+  static constexpr int DSROW = (EB == 2) ? 72 : 144;  // padded [key][32 q] row of the dS buffer
+  static constexpr int DSBUF = 32 * DSROW;
+  static constexpr int KGQ = DQK / 16;
+  static constexpr int KGV = DV / 16;
+  static constexpr int DBQ = DQK / 32;
+  static constexpr int DBV = DV / 32;
+  static constexpr int NQU = (32 * UPR_K + kBwdThreads - 1) / kBwdThreads;
+  static constexpr int NOU = (32 * UPR_V + kBwdThreads - 1) / kBwdThreads;
+  static constexpr int smem_bytes(int nw) { return nw * PAIR + PAIR + nw * DSBUF; }
+  static constexpr int max_tiles(int lds_budget) {
+    int nw = (lds_budget - PAIR) / (PAIR + DSBUF);
+    return nw > kBwdWaves ? kBwdWaves : nw;
+  }
+};
+
+// Column fragment from the (unswizzled, padded) dS buffer: slot j<4 -> buf[rowA+j][n32],
+// slot j>=4 -> buf[rowB+j-4][n32].
+template <typename T, int ROWB>
+HSTU_DEV typename Elem<T>::Frag dsbuf_col_frag(const char* buf, int rowA, int rowB, int lane) {
+  typename Elem<T>::Frag f;
+  if constexpr (Elem<T>::kBytes == 2) {
+    const int i16 = lane & 15;
+    const int col = (((lane >> 4) & 1) << 4) + ((i16 & 3) << 2);
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, buf + (rowA + (i16 >> 2)) * ROWB + col * 2));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, buf + (rowB + (i16 >> 2)) * ROWB + col * 2));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 ab = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    f.v = __builtin_bit_cast(typename Elem<T>::vec8, ab);
+  } else {
+    const int col = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f.v[j] = *LDS_PTR(const float, buf + (rowA + j) * ROWB + col * 4);
+      f.v[4 + j] = *LDS_PTR(const float, buf + (rowB + j) * ROWB + col * 4);
+    }
+  }
+  return f;
+}
+
+template <typename T, int DQK, int DV>
+__global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAttnBwdParams bp, int nkb, int nw,
+                                                                    float* dq_accum) {
+  using C = BwdCfg<T, DQK, DV>;
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const HstuAttnParams& p = bp.fwd;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n32 = lane & 31, hf = lane >> 5;
+
+  // ---- work decode (same grouping as forward: key blocks of one (user, head) adjacent)
+  const int bid = blockIdx.x;
+  const int grp = bid / (8 * nkb), rem = bid % (8 * nkb);
+  const int kb = rem / 8;
+  const int uh = grp * 8 + (rem & 7);
+  if (uh >= p.batch * p.heads) return;
+  const int b = uh / p.heads, hd = uh % p.heads;
+  const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
+  const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
+  const int kb0 = kb * 32 * nw;
+  if (kb0 >= len) return;
+  const MaskCtx mc = make_mask_ctx(p, b, len);
+
+  char* const stage = smem + nw * C::PAIR;           // Q_i tile then dO_i tile
+  char* const dsbuf = stage + C::PAIR;               // nw buffers of [32 keys][32 q]
+  const int k0w = kb0 + 32 * wave;                   // first key of this wave's tile
+  const bool tile_owner = wave < nw && k0w < len;
+
+  const char* qbase = (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
+  const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
+  const char* vbase = (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * C::EB;
+  const char* dobase = (const char*)bp.dout + (off0 * bp.do_row_stride + (int64_t)hd * bp.do_head_stride) * C::EB;
+  const int64_t q_rs = p.q_row_stride * C::EB, k_rs = p.k_row_stride * C::EB, v_rs = p.v_row_stride * C::EB,
+                do_rs = bp.do_row_stride * C::EB;
+
+  // ---- resident K/V block -> LDS (zero-filled past len / past the real head dims)
+  {
+    const int nrows = 32 * nw;
+    for (int u = tid; u < nrows * C::UPR_K; u += kBwdThreads) {
+      const int row = u / C::UPR_K, unit = u % C::UPR_K;
+      const bool ok = (kb0 + row < len) && (unit * C::EPU < p.dqk);
+      u32x4 z = {0u, 0u, 0u, 0u};
+      u32x4 x = ok ? gload16(kbase + (int64_t)(kb0 + row) * k_rs + unit * 16) : z;
+      *LDS_PTR(u32x4, smem + (row >> 5) * C::PAIR + tile_off<C::UPR_K>(row & 31, unit)) = x;
+    }
+    for (int u = tid; u < nrows * C::UPR_V; u += kBwdThreads) {
+      const int row = u / C::UPR_V, unit = u % C::UPR_V;
+      const bool ok = (kb0 + row < len) && (unit * C::EPU < p.dv);
+      u32x4 z = {0u, 0u, 0u, 0u};
+      u32x4 x = ok ? gload16(vbase + (int64_t)(kb0 + row) * v_rs + unit * 16) : z;
+      *LDS_PTR(u32x4, smem + (row >> 5) * C::PAIR + C::KT + tile_off<C::UPR_V>(row & 31, unit)) = x;
+    }
+  }
+
+  // ---- query-tile range: rows at or below the block's first key; contextual rows (id 0)
+  // see every key, so start from 0 when they exist (inactive pairs are skipped per wave)
+  const int it_lo = (mc.ctx > 0) ? 0 : (kb0 >> 5);
+  const int it_hi = (len + 31) >> 5;
+  const int kb_hi = min(kb0 + 32 * nw, len);        // one past the last key of this block
+
+  f32x16 dk_acc[C::DBQ], dv_acc[C::DBV];
+#pragma unroll
+  for (int d = 0; d < C::DBQ; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk_acc[d][r] = 0.f;
+#pragma unroll
+  for (int d = 0; d < C::DBV; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv_acc[d][r] = 0.f;
+
+  u32x4 qreg[C::NQU], oreg[C::NOU];
+  tile_gload<T, DQK, C::NQU, kBwdThreads>(qreg, qbase, q_rs, it_lo * 32, len, p.dqk, tid);
+  tile_gload<T, DV, C::NOU, kBwdThreads>(oreg, dobase, do_rs, it_lo * 32, len, p.dv, tid);
+  tile_lds_write<T, DQK, C::NQU, kBwdThreads>(qreg, stage, tid);
+  tile_lds_write<T, DV, C::NOU, kBwdThreads>(oreg, stage + C::KT, tid);
+  __syncthreads();
+
+  const float ds_scale = p.scale * p.alpha;
+  const int key = k0w + n32;
+  const bool key_ok = tile_owner && key < len;
+
+  for (int it = it_lo; it < it_hi; ++it) {
+    const int i0 = it << 5;
+    const bool more = it + 1 < it_hi;
+    if (more) {
+      tile_gload<T, DQK, C::NQU, kBwdThreads>(qreg, qbase, q_rs, i0 + 32, len, p.dqk, tid);
+      tile_gload<T, DV, C::NOU, kBwdThreads>(oreg, dobase, do_rs, i0 + 32, len, p.dv, tid);
+    }
+
+    // ------------------------------ phase 1 ------------------------------
+    if (tile_owner && mc.pair_may_be_active(i0, 32, k0w, 32)) {
+      const char* Kw = smem + wave * C::PAIR;
+      const char* Vw = Kw + C::KT;
+      const char* Qs = stage;
+      const char* dOs = stage + C::KT;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kg = 0; kg < C::KGQ; ++kg) {
+        const int e0 = hf * (DQK / 2) + kg * 8;
+        Frag a = lds_row_frag<T, C::UPR_K>(Qs, n32, e0);
+        Frag bb = lds_row_frag<T, C::UPR_K>(Kw, n32, e0);
+        s = E::mma(a, bb, s);
+      }
+#pragma unroll
+      for (int kg = 0; kg < C::KGV; ++kg) {
+        const int e0 = hf * (DV / 2) + kg * 8;
+        Frag a = lds_row_frag<T, C::UPR_V>(dOs, n32, e0);
+        Frag bb = lds_row_frag<T, C::UPR_V>(Vw, n32, e0);
+        dp = E::mma(a, bb, dp);
+      }
+      // C layout: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf
+      Frag pb[2], dsb[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const float x = s[r] * p.alpha;
+        const float sg = fast_sigmoid(x);
+        const bool ok = key_ok && qi < len && mc.valid(qi, key);
+        const float pv = ok ? x * sg * p.scale : 0.f;
+        const float dsv = ok ? dp[r] * sg * (1.f + x * (1.f - sg)) * ds_scale : 0.f;
+        E::set(pb[r >> 3], r & 7, pv);
+        E::set(dsb[r >> 3], r & 7, dsv);
+      }
+      // dV_w^T[dv][key] += dO_i^T[dv][q] P[q][key]
+#pragma unroll
+      for (int d = 0; d < C::DBV; ++d)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          Frag a = lds_col_frag<T, C::UPR_V>(dOs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+          dv_acc[d] = E::mma(a, pb[ks], dv_acc[d]);
+        }
+      // dK_w^T[d][key] += Q_i^T[d][q] dS[q][key]
+#pragma unroll
+      for (int d = 0; d < C::DBQ; ++d)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          Frag a = lds_col_frag<T, C::UPR_K>(Qs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+          dk_acc[d] = E::mma(a, dsb[ks], dk_acc[d]);
+        }
+      // publish dS as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3), rq = 0..3
+      char* myds = dsbuf + wave * C::DSBUF + n32 * C::DSROW;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int qloc = 4 * hf + 8 * rq;
+        if constexpr (C::EB == 2) {
+          typedef T t4 __attribute__((ext_vector_type(4)));
+          t4 v4 = {dsb[rq >> 1].v[(rq & 1) * 4 + 0], dsb[rq >> 1].v[(rq & 1) * 4 + 1], dsb[rq >> 1].v[(rq & 1) * 4 + 2],
+                   dsb[rq >> 1].v[(rq & 1) * 4 + 3]};
+          *LDS_PTR(u32x2, myds + qloc * 2) = __builtin_bit_cast(u32x2, v4);
+        } else {
+          f32x4 v4 = {dsb[rq >> 1].v[(rq & 1) * 4 + 0], dsb[rq >> 1].v[(rq & 1) * 4 + 1], dsb[rq >> 1].v[(rq & 1) * 4 + 2],
+                      dsb[rq >> 1].v[(rq & 1) * 4 + 3]};
+          *LDS_PTR(f32x4, myds + qloc * 4) = v4;
+        }
+      }
+    }
+    __syncthreads();  // dS of every owner visible; everybody is done reading the stage
+
+    if (more) {
+      tile_lds_write<T, DQK, C::NQU, kBwdThreads>(qreg, stage, tid);
+      tile_lds_write<T, DV, C::NOU, kBwdThreads>(oreg, stage + C::KT, tid);
+    }
+
+    // ------------------------------ phase 2 ------------------------------
+    if (wave < C::DBQ) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int w2 = 0; w2 < nw; ++w2) {
+        const int k0 = kb0 + 32 * w2;
+        if (k0 >= len || !mc.pair_may_be_active(i0, 32, k0, 32)) continue;   // uniform
+        const char* Kt = smem + w2 * C::PAIR;
+        const char* ds = dsbuf + w2 * C::DSBUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int ra = 16 * ks + 8 * hf;
+          Frag a = lds_col_frag<T, C::UPR_K>(Kt, ra, ra + 4, 32 * wave, lane);      // K^T[d][key]
+          Frag bb = dsbuf_col_frag<T, C::DSROW>(ds, ra, ra + 4, lane);             // dS^T[key][q]
+          acc = E::mma(a, bb, acc);
+        }
+      }
+      // C layout: column n32 = query row, register r = d within the 32-block
+      const int qrow = i0 + n32;
+      if (qrow < len) {
+        if (dq_accum == nullptr) {
+          char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int d0 = 32 * wave + 8 * rq + 4 * hf;
+            if (d0 < p.dqk) store4<T>(dqrow, d0, acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+          }
+        } else {
+          float* arow = dq_accum + ((off0 + qrow) * p.heads + hd) * (int64_t)p.dqk;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int d = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (d < p.dqk) atomicAdd(arow + d, acc[r]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // next stage visible; dS buffers free again
+  }
+  (void)kb_hi;
+
+  // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv
+  if (key_ok) {
+    char* dkrow = (char*)bp.dk + ((off0 + key) * bp.dk_row_stride + (int64_t)hd * bp.dk_head_stride) * C::EB;
+    char* dvrow = (char*)bp.dv + ((off0 + key) * bp.dv_row_stride + (int64_t)hd * bp.dv_head_stride) * C::EB;
+#pragma unroll
+    for (int d = 0; d < C::DBQ; ++d)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = 32 * d + 8 * rq + 4 * hf;
+        if (d0 < p.dqk)
+          store4<T>(dkrow, d0, dk_acc[d][4 * rq], dk_acc[d][4 * rq + 1], dk_acc[d][4 * rq + 2], dk_acc[d][4 * rq + 3]);
+      }
+#pragma unroll
+    for (int d = 0; d < C::DBV; ++d)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = 32 * d + 8 * rq + 4 * hf;
+        if (d0 < p.dv)
+          store4<T>(dvrow, d0, dv_acc[d][4 * rq], dv_acc[d][4 * rq + 1], dv_acc[d][4 * rq + 2], dv_acc[d][4 * rq + 3]);
+      }
+  }
+}
+
+// fp32 dq accumulator (rows, H, dqk) -> dq in the I/O dtype (strided)
+template <typename T>
+__global__ void hstu_dq_convert_kernel(const float* acc, void* dq, int64_t rows, int heads, int dqk, int64_t row_stride,
+                                       int64_t head_stride) {
+  const int64_t n = rows * heads * (int64_t)dqk;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % dqk);
+    const int64_t rh = i / dqk;
+    const int h = (int)(rh % heads);
+    const int64_t r = rh / heads;
+    ((T*)dq)[r * row_stride + h * head_stride + d] = (T)acc[i];
+  }
+}
+
+}  // namespace hstu

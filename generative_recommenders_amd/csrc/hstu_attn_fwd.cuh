@@ -1,0 +1,243 @@
+// HSTU attention forward for gfx950 (hand-written, MFMA 32x32, wave64).
+//
+//   O[i,:] = sum_j silu(alpha <q_i,k_j>) * scale * M[i,j] * v_j        (per user, per head)
+//
+// Replaces triton_hstu_attention_fwd / triton_cached_hstu_mha
+// (ops/triton/triton_hstu_attention.py:1767-1846, 2095-2170) and hstu::hstu_mha_fwd
+// (ops/cpp/hstu_attention/flash_api.cpp:34-110).  Semantics follow the reference
+// PyTorch path, ops/pytorch/pt_hstu_attention.py:129-235.
+//
+// Mapping.  One workgroup (4 waves) = one (user, head, block of 128 query rows);
+// wave w owns query rows [q0+32w, q0+32w+32).  Everything is computed "transposed"
+// so that the query index lives on the lane axis of every fragment:
+//     S^T  = K_j  Q^T      A = K tile rows (LDS, b128), B = Q fragment (registers)
+//     P^T  = silu(alpha S^T) * scale * M      in the MFMA C layout == the B layout
+//                                              of the next MFMA (no shuffles, no LDS)
+//     O^T += V_j^T P^T     A = V tile through the LDS transpose read
+// K/V tiles of 32 keys stream through a 2-stage LDS ring; the global loads of
+// tile t+1 are issued before the math of tile t and written to LDS after it.
+// HSTU has no softmax, so there is no running max / rescale: tiles are independent.
+#pragma once
+#include "hstu_common.cuh"
+
+namespace hstu {
+
+constexpr int kFwdThreads = 256;
+constexpr int kFwdRowsPerBlock = 128;
+
+template <typename T, int DQK, int DV>
+struct FwdCfg {
+  static constexpr int EB = Elem<T>::kBytes;
+  static constexpr int EPU = 16 / EB;            // elements per 16-byte unit
+  static constexpr int UPR_K = DQK * EB / 16;    // units per K row
+  static constexpr int UPR_V = DV * EB / 16;
+  static constexpr int KT = 32 * DQK * EB;       // bytes of a 32-row K tile
+  static constexpr int VT = 32 * DV * EB;
+  static constexpr int STAGE = KT + VT;
+  static constexpr int KG = DQK / 16;            // 16-wide contraction groups of QK^T
+  static constexpr int DB = DV / 32;             // 32-wide output blocks
+  static constexpr int NKU = (32 * UPR_K + kFwdThreads - 1) / kFwdThreads;  // staged units / thread
+  static constexpr int NVU = (32 * UPR_V + kFwdThreads - 1) / kFwdThreads;
+  static constexpr int SMEM = 2 * STAGE;
+};
+
+// Cooperative global -> register load of one [32][D] tile (rows row0.., zero-filled
+// past `len` and past the real head dim), and the matching register -> LDS write.
+template <typename T, int D, int NU, int NTHREADS>
+HSTU_DEV void tile_gload(u32x4 (&reg)[NU], const char* base, int64_t row_stride_bytes, int row0, int len,
+                         int real_d, int tid) {
+  constexpr int UPR = D * Elem<T>::kBytes / 16;
+  constexpr int EPU = 16 / Elem<T>::kBytes;
+#pragma unroll
+  for (int t = 0; t < NU; ++t) {
+    const int u = tid + t * NTHREADS;
+    const int row = u / UPR, unit = u % UPR;
+    const bool ok = (u < 32 * UPR) && (row0 + row < len) && (unit * EPU < real_d);
+    u32x4 z = {0u, 0u, 0u, 0u};
+    reg[t] = ok ? gload16(base + (int64_t)(row0 + row) * row_stride_bytes + unit * 16) : z;
+  }
+}
+
+template <typename T, int D, int NU, int NTHREADS>
+HSTU_DEV void tile_lds_write(const u32x4 (&reg)[NU], char* tile, int tid) {
+  constexpr int UPR = D * Elem<T>::kBytes / 16;
+#pragma unroll
+  for (int t = 0; t < NU; ++t) {
+    const int u = tid + t * NTHREADS;
+    if (u < 32 * UPR) *LDS_PTR(u32x4, tile + tile_off<UPR>(u / UPR, u % UPR)) = reg[t];
+  }
+}
+
+// Row fragment straight from global memory: elements [e0, e0+8) of one row, zero if
+// !ok.  Used for operands a wave keeps in registers for its whole lifetime (Q here).
+template <typename T>
+HSTU_DEV typename Elem<T>::Frag global_row_frag(const char* row_ptr, int e0, bool ok) {
+  typename Elem<T>::Frag f;
+  u32x4 z = {0u, 0u, 0u, 0u};
+  if constexpr (Elem<T>::kBytes == 2) {
+    u32x4 x = ok ? gload16(row_ptr + e0 * 2) : z;
+    f.v = __builtin_bit_cast(typename Elem<T>::vec8, x);
+  } else {
+    u32x4 x0 = ok ? gload16(row_ptr + e0 * 4) : z;
+    u32x4 x1 = ok ? gload16(row_ptr + e0 * 4 + 16) : z;
+    f32x4 a = __builtin_bit_cast(f32x4, x0), b = __builtin_bit_cast(f32x4, x1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  }
+  return f;
+}
+
+// Store a transposed accumulator block: this lane holds, for output row `row_ptr`,
+// the 4 consecutive columns d0..d0+3 in acc[4*rq .. 4*rq+3].
+template <typename T>
+HSTU_DEV void store4(char* row_ptr, int d0, float x0, float x1, float x2, float x3) {
+  if constexpr (Elem<T>::kBytes == 2) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 v = {(T)x0, (T)x1, (T)x2, (T)x3};
+    *reinterpret_cast<u32x2*>(row_ptr + d0 * 2) = __builtin_bit_cast(u32x2, v);
+  } else {
+    f32x4 v = {x0, x1, x2, x3};
+    *reinterpret_cast<f32x4*>(row_ptr + d0 * 4) = v;
+  }
+}
+
+template <typename T, int DQK, int DV>
+__global__ __launch_bounds__(kFwdThreads) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb) {
+  using C = FwdCfg<T, DQK, DV>;
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n32 = lane & 31, hf = lane >> 5;
+
+  // ---- work decode: 8 consecutive (user,head) pairs share a dispatch group so that the
+  // query blocks of one (user,head) land on the same XCD (block id mod 8) back to back and
+  // re-read K/V from that XCD's L2; heavier (later) query blocks are dispatched first.
+  const int bid = blockIdx.x;
+  const int grp = bid / (8 * nqb), rem = bid % (8 * nqb);
+  const int qb = nqb - 1 - rem / 8;
+  const int uh = grp * 8 + (rem & 7);
+  if (uh >= p.batch * p.heads) return;
+  const int b = uh / p.heads, hd = uh % p.heads;
+
+  const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
+  const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
+  const int nq_rows = p.delta_q > 0 ? min(p.delta_q, len) : len;
+  const int i_shift = p.delta_q > 0 ? len - nq_rows : 0;      // logical position of q row 0
+  const int64_t q_base = p.delta_q > 0 ? (int64_t)b * p.delta_q + (p.delta_q - nq_rows) : off0;
+  const int q0 = qb * kFwdRowsPerBlock;
+  if (q0 >= nq_rows) return;
+
+  const MaskCtx mc = make_mask_ctx(p, b, len);
+  const int r0 = q0 + 32 * wave;                 // first q row of this wave
+  const bool wave_active = r0 < nq_rows;
+  const int my_row = r0 + n32;
+  const bool row_ok = my_row < nq_rows;
+  const int qi = my_row + i_shift;               // logical position of this lane's query
+
+  // ---- key range visited by this workgroup (conservative; the per-element mask is exact)
+  const int i_first = q0 + i_shift;
+  const int i_last = min(q0 + kFwdRowsPerBlock, nq_rows) - 1 + i_shift;
+  const bool ctx_rows = mc.ctx > 0 && i_first < mc.ctx;
+  const int kv_hi = ctx_rows ? len : min(len, i_last + 1);
+  int kv_lo = 0;
+  if (mc.win > 0 && mc.full == 0 && !ctx_rows) {
+    const int x = mc.id_of(i_first) - mc.win;
+    const int pos = x <= 0 ? 0 : (mc.ctx > 0 ? x + mc.ctx - 1 : x);
+    kv_lo = (pos >> 5) << 5;
+  }
+  const int ntiles = (kv_hi - kv_lo + 31) >> 5;
+
+  // ---- Q fragment of this wave (B operand of S^T = K Q^T): lane (q = n32, hf) holds
+  // elements hf*DQK/2 + 8*kg .. +8 of its row: one contiguous half row per lane.
+  Frag qf[C::KG];
+  {
+    const char* qrow = (const char*)p.q + ((q_base + my_row) * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
+#pragma unroll
+    for (int kg = 0; kg < C::KG; ++kg) {
+      const int e0 = hf * (DQK / 2) + kg * 8;
+      qf[kg] = global_row_frag<T>(qrow, e0, row_ok && e0 < p.dqk);
+    }
+  }
+
+  const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
+  const char* vbase = (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * C::EB;
+  const int64_t k_rs = p.k_row_stride * C::EB, v_rs = p.v_row_stride * C::EB;
+
+  f32x16 oacc[C::DB];
+#pragma unroll
+  for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+
+  u32x4 kreg[C::NKU], vreg[C::NVU];
+  if (ntiles > 0) {
+    tile_gload<T, DQK, C::NKU, kFwdThreads>(kreg, kbase, k_rs, kv_lo, len, p.dqk, tid);
+    tile_gload<T, DV, C::NVU, kFwdThreads>(vreg, vbase, v_rs, kv_lo, len, p.dv, tid);
+    tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, smem, tid);
+    tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, smem + C::KT, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int j0 = kv_lo + (t << 5);
+    const bool more = t + 1 < ntiles;
+    if (more) {  // issue next tile's global loads; they land while this tile is computed
+      tile_gload<T, DQK, C::NKU, kFwdThreads>(kreg, kbase, k_rs, j0 + 32, len, p.dqk, tid);
+      tile_gload<T, DV, C::NVU, kFwdThreads>(vreg, vbase, v_rs, j0 + 32, len, p.dv, tid);
+    }
+    if (wave_active && mc.pair_may_be_active(r0 + i_shift, 32, j0, 32)) {
+      const char* Kt = smem + (t & 1) * C::STAGE;
+      const char* Vt = Kt + C::KT;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int kg = 0; kg < C::KG; ++kg) {
+        Frag a = lds_row_frag<T, C::UPR_K>(Kt, n32, hf * (DQK / 2) + kg * 8);
+        s = E::mma(a, qf[kg], s);
+      }
+      Frag pb[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const float x = s[r] * p.alpha;
+        const float pv = x * fast_sigmoid(x) * p.scale;
+        const bool ok = row_ok && key < len && mc.valid(qi, key);
+        E::set(pb[r >> 3], r & 7, ok ? pv : 0.f);
+      }
+#pragma unroll
+      for (int d = 0; d < C::DB; ++d) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          Frag a = lds_col_frag<T, C::UPR_V>(Vt, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+          oacc[d] = E::mma(a, pb[ks], oacc[d]);
+        }
+      }
+    }
+    if (more) {
+      char* nxt = smem + ((t + 1) & 1) * C::STAGE;
+      tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, nxt, tid);
+      tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, nxt + C::KT, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: O^T accumulators -> out rows
+  if (row_ok) {
+    char* orow = (char*)p.out + ((q_base + my_row) * p.o_row_stride + (int64_t)hd * p.o_head_stride) * C::EB;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = 32 * d + 8 * rq + 4 * hf;
+        if (d0 < p.dv) store4<T>(orow, d0, oacc[d][4 * rq], oacc[d][4 * rq + 1], oacc[d][4 * rq + 2], oacc[d][4 * rq + 3]);
+      }
+    }
+  }
+}
+
+}  // namespace hstu

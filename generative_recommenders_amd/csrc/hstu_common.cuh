@@ -1,0 +1,213 @@
+// Shared device-side building blocks for the gfx950 HSTU kernels.
+//
+// Conventions used by every attention kernel in this directory
+// ------------------------------------------------------------
+// * One wavefront = 64 lanes.  lane = threadIdx.x & 63, `n32 = lane & 31`,
+//   `hf = lane >> 5` (which half of the wave), `g16 = lane >> 4`, `i16 = lane & 15`.
+// * The matrix instruction is the 32x32 MFMA (v_mfma_f32_32x32x16_{bf16,f16}; for
+//   fp32 I/O eight v_mfma_f32_32x32x2_f32).  A "fragment" is 8 elements per lane:
+//       A operand:  A[row = n32][k = kk(hf, j)]      j = 0..7
+//       B operand:  B[k = kk(hf, j)][col = n32]
+//       C/D      :  C[row = (r&3) + 8*(r>>2) + 4*hf][col = n32]   r = 0..15
+//   The hardware pairs A's (hf, j) with B's (hf, j); which logical contraction
+//   index that slot carries is OUR choice as long as both operands agree.
+// * Tiles in LDS are row-major [32 rows][D] with the 16-byte units of each row
+//   XOR-swizzled (tile_off) so that a 16-lane group reading one unit column of 16
+//   different rows hits 16 different 16-byte bank slots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hstu_hip.h"
+
+namespace hstu {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define HSTU_DEV __device__ __forceinline__
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---------------------------------------------------------------------------
+// element-type traits
+// ---------------------------------------------------------------------------
+template <typename T> struct Elem;
+
+template <> struct Elem<bf16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kDtype = HSTU_DTYPE_BF16;
+  typedef bf16_t vec8 __attribute__((ext_vector_type(8)));
+  struct Frag { vec8 v; };
+  static HSTU_DEV f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+  }
+  static HSTU_DEV void set(Frag& f, int j, float x) { f.v[j] = (bf16_t)x; }
+};
+
+template <> struct Elem<f16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kDtype = HSTU_DTYPE_F16;
+  typedef f16_t vec8 __attribute__((ext_vector_type(8)));
+  struct Frag { vec8 v; };
+  static HSTU_DEV f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, c, 0, 0, 0);
+  }
+  static HSTU_DEV void set(Frag& f, int j, float x) { f.v[j] = (f16_t)x; }
+};
+
+template <> struct Elem<float> {
+  static constexpr int kBytes = 4;
+  static constexpr int kDtype = HSTU_DTYPE_F32;
+  typedef float vec8 __attribute__((ext_vector_type(8)));
+  struct Frag { vec8 v; };
+  // exact fp32: slot (hf, j) of the 16-wide k-group is fed to the j-th 32x32x2 MFMA.
+  static HSTU_DEV f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
+    return c;
+  }
+  static HSTU_DEV void set(Frag& f, int j, float x) { f.v[j] = x; }
+};
+
+template <typename T> HSTU_DEV float to_f32(T x) { return (float)x; }
+
+// ---------------------------------------------------------------------------
+// LDS tile layout
+// ---------------------------------------------------------------------------
+// Units are 16 bytes.  UPR = units per row (power of two).  Returns the byte
+// offset of unit `u` of row `r` inside a tile of 32 (or more) rows.
+template <int UPR> HSTU_DEV int tile_off(int r, int u) {
+  static_assert((UPR & (UPR - 1)) == 0, "UPR must be a power of two");
+  if constexpr (UPR >= 16) {
+    return (r * UPR + (u ^ (r & 15))) << 4;
+  } else {
+    constexpr int RPB = 16 / UPR;  // rows per 256-byte bank row
+    return (r * UPR + (u ^ ((r / RPB) & (UPR - 1)))) << 4;
+  }
+}
+
+// Fragment of a row-major tile for a contraction along the row:
+// elements [e0, e0+8) of row `row`.  16-bit: one unit; fp32: two units.
+template <typename T, int UPR>
+HSTU_DEV typename Elem<T>::Frag lds_row_frag(const char* tile, int row, int e0) {
+  typename Elem<T>::Frag f;
+  if constexpr (Elem<T>::kBytes == 2) {
+    u32x4 x = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, e0 >> 3));
+    f.v = __builtin_bit_cast(typename Elem<T>::vec8, x);
+  } else {
+    u32x4 x0 = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, (e0 >> 2)));
+    u32x4 x1 = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, (e0 >> 2) + 1));
+    f32x4 a = __builtin_bit_cast(f32x4, x0), b = __builtin_bit_cast(f32x4, x1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  }
+  return f;
+}
+
+// Fragment for a contraction ACROSS rows ("transposed" use of a row-major tile):
+// slot j<4 -> tile[rowA + j][col], slot j>=4 -> tile[rowB + j-4][col], where
+// col = colblk + n32.  16-bit types use the hardware transpose read
+// (ds_read_b64_tr_b16: the 16 lanes of a group fetch a [4 rows][16 cols] block,
+// lane i supplying the address of row i/4, cols 4*(i%4)..+3, and receive column i
+// of the 4 rows); fp32 gathers with eight ds_read_b32.
+template <typename T, int UPR>
+HSTU_DEV typename Elem<T>::Frag lds_col_frag(const char* tile, int rowA, int rowB, int colblk, int lane) {
+  typename Elem<T>::Frag f;
+  if constexpr (Elem<T>::kBytes == 2) {
+    const int i16 = lane & 15;
+    const int col = colblk + (((lane >> 4) & 1) << 4) + ((i16 & 3) << 2);  // first of this lane's 4 cols
+    const int sub = (col & 7) << 1;                                         // byte offset inside the unit
+    const int ra = rowA + (i16 >> 2), rb = rowB + (i16 >> 2);
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + tile_off<UPR>(ra, col >> 3) + sub));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + tile_off<UPR>(rb, col >> 3) + sub));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 ab = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    f.v = __builtin_bit_cast(typename Elem<T>::vec8, ab);
+  } else {
+    const int col = colblk + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f.v[j] = *LDS_PTR(const float, tile + tile_off<UPR>(rowA + j, col >> 2) + ((col & 3) << 2));
+      f.v[4 + j] = *LDS_PTR(const float, tile + tile_off<UPR>(rowB + j, col >> 2) + ((col & 3) << 2));
+    }
+  }
+  return f;
+}
+
+// ---------------------------------------------------------------------------
+// index loads (int32 | int64 offsets / targets)
+// ---------------------------------------------------------------------------
+HSTU_DEV int64_t load_index(const void* p, int64_t i, int is64) {
+  return is64 ? ((const int64_t*)p)[i] : (int64_t)((const int32_t*)p)[i];
+}
+
+// ---------------------------------------------------------------------------
+// mask algebra (reference: ops/pytorch/pt_hstu_attention.py:32-84)
+// ---------------------------------------------------------------------------
+struct MaskCtx {
+  int len;        // L of this user
+  int max_id;     // L (c==0) or L-c+1, minus num_targets if present
+  int ctx;        // contextual_seq_len
+  int win;        // max_attn_len (0 = none)
+  int full;       // min_full_attn_seq_len
+  int has_targets;
+
+  HSTU_DEV int id_of(int pos) const {
+    int id = ctx > 0 ? max(pos - ctx + 1, 0) : pos;
+    return has_targets ? min(id, max_id) : id;
+  }
+  // row position i (query), col position j (key); both < len
+  HSTU_DEV bool valid(int i, int j) const {
+    const int idi = id_of(i), idj = id_of(j);
+    const int d = idi - idj;
+    bool m = (i == j) | (d > 0);
+    if (win > 0) m = m & ((d <= win) | ((full > 0) & (idi >= max_id - full)));
+    if (ctx > 0) m = m | ((idi == 0) & (idj < max_id));
+    return m;
+  }
+  // Conservative test: can ANY (i, j) with i in [i0, i0+ni), j in [j0, j0+nj) be valid?
+  HSTU_DEV bool pair_may_be_active(int i0, int ni, int j0, int nj) const {
+    if (i0 >= len || j0 >= len) return false;
+    const int i1 = min(i0 + ni, len) - 1;      // last row
+    const int j1 = min(j0 + nj, len) - 1;      // last col
+    const bool ctx_rows = (ctx > 0) && (i0 < ctx);  // rows with id 0 see every non-target col
+    if (ctx_rows) return true;
+    if (i1 < j0) return false;                  // strictly above the diagonal
+    if (win > 0 && full == 0) {
+      // smallest distance in the block: first row vs last col
+      if (id_of(i0) - id_of(j1) > win && !(i0 <= j1)) return false;
+    }
+    return true;
+  }
+};
+
+HSTU_DEV MaskCtx make_mask_ctx(const HstuAttnParams& p, int b, int len) {
+  MaskCtx m;
+  m.len = len;
+  m.ctx = p.contextual_seq_len;
+  m.win = p.max_attn_len;
+  m.full = p.min_full_attn_seq_len;
+  m.has_targets = p.num_targets != nullptr;
+  int max_id = len;
+  if (m.ctx > 0) max_id = max_id - m.ctx + 1;
+  if (m.has_targets) max_id -= (int)load_index(p.num_targets, b, p.targets_dtype);
+  m.max_id = max_id;
+  return m;
+}
+
+// silu(s) = s * sigmoid(s), fp32, hardware exp2 / rcp (1 ulp each)
+HSTU_DEV float fast_sigmoid(float s) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * s));
+}
+
+// 16-byte global load / store helpers
+HSTU_DEV u32x4 gload16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+HSTU_DEV void gstore16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+}  // namespace hstu

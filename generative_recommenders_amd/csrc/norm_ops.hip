@@ -1,0 +1,604 @@
+// Row-wise normalisation kernels around the HSTU projections (gfx950, HBM-bound).
+//
+// One wavefront owns one row at a time (grid-stride over rows): each lane loads its
+// 16-byte pieces of the row once, keeps them in registers, reduces with wave shuffles,
+// and writes once.  Weight gradients are accumulated per lane across all the rows a
+// wave visits (lanes own fixed columns), reduced across the workgroup's waves through
+// LDS and written as one fp32 partial per workgroup; a second small kernel sums the
+// partials.  All math is fp32, outputs are cast to the I/O dtype, like the reference:
+//   ops/pytorch/pt_layer_norm.py:24-38, ops/pytorch/pt_hstu_linear.py:23-65;
+// kernels replaced: ops/triton/triton_layer_norm.py:77-309,
+// ops/triton/triton_hstu_linear.py:48-337 (LN * u), :570-1036 (GroupNorm * u).
+#include "hstu_common.cuh"
+#include "capi_internal.h"
+
+namespace hstu {
+
+constexpr int kNormThreads = 256;
+constexpr int kNormWaves = kNormThreads / 64;
+// register-resident pieces per lane: 16-bit x8 -> dim <= 1024, fp32 x4 -> dim <= 1024, scalar -> dim <= 512
+template <int VEC> constexpr int max_chunks() { return VEC == 8 ? 2 : (VEC == 4 ? 4 : 8); }
+constexpr int kMaxNormBlocks = 1024;
+
+template <typename T, int VEC> struct RowVec {
+  float v[VEC];
+};
+
+template <typename T, int VEC>
+HSTU_DEV void load_vec(RowVec<T, VEC>& r, const T* p, bool ok) {
+  if (!ok) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r.v[i] = 0.f;
+    return;
+  }
+  if constexpr (VEC == 1) {
+    r.v[0] = (float)p[0];
+  } else if constexpr (sizeof(T) == 2) {  // VEC == 8
+    u32x4 x = *reinterpret_cast<const u32x4*>(p);
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    t8 t = __builtin_bit_cast(t8, x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (float)t[i];
+  } else {  // fp32, VEC == 4
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = t[i];
+  }
+}
+
+template <typename T, int VEC>
+HSTU_DEV void store_vec(const RowVec<T, VEC>& r, T* p) {
+  if constexpr (VEC == 1) {
+    p[0] = (T)r.v[0];
+  } else if constexpr (sizeof(T) == 2) {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    t8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (T)r.v[i];
+    *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, t);
+  } else {
+    f32x4 t = {r.v[0], r.v[1], r.v[2], r.v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+}
+
+HSTU_DEV float wave_sum(float x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+  return x;
+}
+
+// ------------------------------------------------------------------ layer norm
+template <typename T, int VEC>
+__global__ __launch_bounds__(kNormThreads) void layer_norm_fwd_kernel(const T* x, const T* w, const T* b, T* y,
+                                                                      float* mean_out, float* rstd_out, int64_t rows,
+                                                                      int dim, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
+  RowVec<T, VEC> wv[max_chunks<VEC>()], bv[max_chunks<VEC>()];
+#pragma unroll
+  for (int k = 0; k < max_chunks<VEC>(); ++k) {
+    const int c = (k * 64 + lane) * VEC;
+    load_vec<T, VEC>(wv[k], w + c, k < nch && c < dim);
+    load_vec<T, VEC>(bv[k], b + c, k < nch && c < dim);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * kNormWaves + wave; row < rows; row += (int64_t)gridDim.x * kNormWaves) {
+    RowVec<T, VEC> xv[max_chunks<VEC>()];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      load_vec<T, VEC>(xv[k], x + row * dim + c, k < nch && c < dim);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s += xv[k].v[i];
+    }
+    const float mean = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      if (k < nch && c < dim) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const float d = xv[k].v[i] - mean; q += d * d; }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / dim + eps);
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      if (k < nch && c < dim) {
+        RowVec<T, VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o.v[i] = (xv[k].v[i] - mean) * rstd * wv[k].v[i] + bv[k].v[i];
+        store_vec<T, VEC>(o, y + row * dim + c);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
+// block-level reduction of per-lane column partials -> one fp32 partial row per workgroup
+template <int VEC>
+HSTU_DEV void block_reduce_cols(float (&acc)[max_chunks<VEC>()][VEC], float* lds, float* out_row, int dim, int nch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // lds: [kNormWaves][dim_padded]
+  const int dpad = nch * 64 * VEC;
+#pragma unroll
+  for (int k = 0; k < max_chunks<VEC>(); ++k)
+    if (k < nch)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) lds[wave * dpad + (k * 64 + lane) * VEC + i] = acc[k][i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < dim; c += kNormThreads) {
+    float s = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < kNormWaves; ++w2) s += lds[w2 * dpad + c];
+    out_row[c] = s;
+  }
+  __syncthreads();
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kNormThreads) void layer_norm_bwd_kernel(const T* dy, const T* x, const T* w,
+                                                                      const float* mean_in, const float* rstd_in, T* dx,
+                                                                      float* partial, int64_t rows, int dim) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
+  RowVec<T, VEC> wv[max_chunks<VEC>()];
+  float dw[max_chunks<VEC>()][VEC], db[max_chunks<VEC>()][VEC];
+#pragma unroll
+  for (int k = 0; k < max_chunks<VEC>(); ++k) {
+    const int c = (k * 64 + lane) * VEC;
+    load_vec<T, VEC>(wv[k], w + c, k < nch && c < dim);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { dw[k][i] = 0.f; db[k][i] = 0.f; }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * kNormWaves + wave; row < rows; row += (int64_t)gridDim.x * kNormWaves) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    RowVec<T, VEC> xh[max_chunks<VEC>()], g[max_chunks<VEC>()];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      const bool ok = k < nch && c < dim;
+      RowVec<T, VEC> dyv;
+      load_vec<T, VEC>(xh[k], x + row * dim + c, ok);
+      load_vec<T, VEC>(dyv, dy + row * dim + c, ok);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float xhat = ok ? (xh[k].v[i] - mean) * rstd : 0.f;
+        xh[k].v[i] = xhat;
+        g[k].v[i] = dyv.v[i] * wv[k].v[i];
+        s1 += g[k].v[i] * xhat;
+        s2 += g[k].v[i];
+        dw[k][i] += dyv.v[i] * xhat;
+        db[k][i] += dyv.v[i];
+      }
+    }
+    const float c1 = wave_sum(s1) / dim, c2 = wave_sum(s2) / dim;
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      if (k < nch && c < dim) {
+        RowVec<T, VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o.v[i] = rstd * (g[k].v[i] - c2 - xh[k].v[i] * c1);
+        store_vec<T, VEC>(o, dx + row * dim + c);
+      }
+    }
+  }
+  block_reduce_cols<VEC>(dw, lds, partial + (int64_t)blockIdx.x * 2 * dim, dim, nch);
+  block_reduce_cols<VEC>(db, lds, partial + (int64_t)blockIdx.x * 2 * dim + dim, dim, nch);
+}
+
+// sums `nparts` partial rows of width `width` -> out[width]
+__global__ void reduce_partials_kernel(const float* partial, int nparts, int stride, int width, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += partial[(int64_t)i * stride + c];
+  out[c] = s;
+}
+
+// ------------------------------------------------------------------ y = u * Norm(attn) [, concat]
+// LN: statistics over the whole row, weight/bias per column.
+// GN: statistics per head (head_dim columns), weight/bias per head.
+template <typename T, int VEC, bool GN>
+__global__ __launch_bounds__(kNormThreads) void norm_mul_fwd_kernel(const T* attn, const T* u, const T* w, const T* b,
+                                                                    T* y, float* mean_out, float* rstd_out,
+                                                                    int64_t rows, int heads, int hdim, float eps,
+                                                                    int concat) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = heads * hdim;
+  const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
+  const int ostride = concat ? 3 * dim : dim;
+  for (int64_t row = (int64_t)blockIdx.x * kNormWaves + wave; row < rows; row += (int64_t)gridDim.x * kNormWaves) {
+    RowVec<T, VEC> xv[max_chunks<VEC>()], uv[max_chunks<VEC>()];
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      const bool ok = k < nch && c < dim;
+      load_vec<T, VEC>(xv[k], attn + row * dim + c, ok);
+      load_vec<T, VEC>(uv[k], u + row * dim + c, ok);
+    }
+    const int ngroups = GN ? heads : 1;
+    const int gdim = GN ? hdim : dim;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int lo = gi * gdim, hi = lo + gdim;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < max_chunks<VEC>(); ++k) {
+        const int c = (k * 64 + lane) * VEC;
+        if (k < nch && c >= lo && c < hi)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) s += xv[k].v[i];
+      }
+      const float mean = wave_sum(s) / gdim;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < max_chunks<VEC>(); ++k) {
+        const int c = (k * 64 + lane) * VEC;
+        if (k < nch && c >= lo && c < hi)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) { const float d = xv[k].v[i] - mean; q += d * d; }
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(q) / gdim + eps);
+      float gw = 0.f, gb = 0.f;
+      if (GN) { gw = (float)w[gi]; gb = (float)b[gi]; }
+#pragma unroll
+      for (int k = 0; k < max_chunks<VEC>(); ++k) {
+        const int c = (k * 64 + lane) * VEC;
+        if (k < nch && c >= lo && c < hi) {
+          RowVec<T, VEC> wv, bv, o;
+          if (!GN) { load_vec<T, VEC>(wv, w + c, true); load_vec<T, VEC>(bv, b + c, true); }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float n = (xv[k].v[i] - mean) * rstd * (GN ? gw : wv.v[i]) + (GN ? gb : bv.v[i]);
+            o.v[i] = uv[k].v[i] * n;
+          }
+          T* yrow = y + row * ostride;
+          if (concat) {
+            store_vec<T, VEC>(uv[k], yrow + c);
+            store_vec<T, VEC>(xv[k], yrow + dim + c);
+            store_vec<T, VEC>(o, yrow + 2 * dim + c);
+          } else {
+            store_vec<T, VEC>(o, yrow + c);
+          }
+        }
+      }
+      if (lane == 0) {
+        if (mean_out) mean_out[row * ngroups + gi] = mean;
+        if (rstd_out) rstd_out[row * ngroups + gi] = rstd;
+      }
+    }
+  }
+}
+
+// backward of the above.  partial row layout per workgroup: [dweight(width) | dbias(width)],
+// width = dim (LN) or heads (GN).
+template <typename T, int VEC, bool GN>
+__global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_kernel(const T* dy, const T* attn, const T* u, const T* w,
+                                                                    const T* b, const float* mean_in,
+                                                                    const float* rstd_in, T* dattn, T* du,
+                                                                    float* partial, int64_t rows, int heads, int hdim,
+                                                                    int concat) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = heads * hdim;
+  const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
+  const int istride = concat ? 3 * dim : dim;
+  const int ngroups = GN ? heads : 1;
+  const int gdim = GN ? hdim : dim;
+  float dw[max_chunks<VEC>()][VEC], db[max_chunks<VEC>()][VEC];   // LN: per column.  GN: slot [0][0..] unused, see ghw/ghb
+#pragma unroll
+  for (int k = 0; k < max_chunks<VEC>(); ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { dw[k][i] = 0.f; db[k][i] = 0.f; }
+  float ghw[16], ghb[16];                             // GN: per-head partials (heads <= 16), lane-local
+#pragma unroll
+  for (int h = 0; h < 16; ++h) { ghw[h] = 0.f; ghb[h] = 0.f; }
+
+  for (int64_t row = (int64_t)blockIdx.x * kNormWaves + wave; row < rows; row += (int64_t)gridDim.x * kNormWaves) {
+    RowVec<T, VEC> xv[max_chunks<VEC>()], uv[max_chunks<VEC>()], gy[max_chunks<VEC>()];
+    const T* dyrow = dy + row * istride;
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      const bool ok = k < nch && c < dim;
+      load_vec<T, VEC>(xv[k], attn + row * dim + c, ok);
+      load_vec<T, VEC>(uv[k], u + row * dim + c, ok);
+      load_vec<T, VEC>(gy[k], dyrow + (concat ? 2 * dim : 0) + c, ok);
+    }
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) {
+      if (gi < ngroups) {
+        const int lo = gi * gdim, hi = lo + gdim;
+        const float mean = mean_in[row * ngroups + gi], rstd = rstd_in[row * ngroups + gi];
+        float gw = 0.f, gb = 0.f;
+        if (GN) { gw = (float)w[gi]; gb = (float)b[gi]; }
+        float s1 = 0.f, s2 = 0.f, hw = 0.f, hb = 0.f;
+        RowVec<T, VEC> gg[max_chunks<VEC>()], xh[max_chunks<VEC>()];
+#pragma unroll
+        for (int k = 0; k < max_chunks<VEC>(); ++k) {
+          const int c = (k * 64 + lane) * VEC;
+          const bool in = k < nch && c >= lo && c < hi;
+          RowVec<T, VEC> wv, bv;
+          if (!GN) { load_vec<T, VEC>(wv, w + c, in); load_vec<T, VEC>(bv, b + c, in); }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float xhat = in ? (xv[k].v[i] - mean) * rstd : 0.f;
+            const float gam = GN ? gw : wv.v[i];
+            const float bet = GN ? gb : bv.v[i];
+            const float dyu = in ? gy[k].v[i] * uv[k].v[i] : 0.f;   // d(norm out)
+            xh[k].v[i] = xhat;
+            gg[k].v[i] = dyu * gam;
+            s1 += gg[k].v[i] * xhat;
+            s2 += gg[k].v[i];
+            if (GN) { hw += dyu * xhat; hb += dyu; }
+            else if (in) { dw[k][i] += dyu * xhat; db[k][i] += dyu; }
+            if (in) uv[k].v[i] = gy[k].v[i] * (gam * xhat + bet);      // du contribution dy * n_hat (reuses uv)
+          }
+        }
+        if (GN) { ghw[gi] += hw; ghb[gi] += hb; }
+        const float c1 = wave_sum(s1) / gdim, c2 = wave_sum(s2) / gdim;
+#pragma unroll
+        for (int k = 0; k < max_chunks<VEC>(); ++k) {
+          const int c = (k * 64 + lane) * VEC;
+          if (k < nch && c >= lo && c < hi) {
+            RowVec<T, VEC> o, o2, e1, e2;
+            if (concat) {
+              load_vec<T, VEC>(e1, dyrow + c, true);          // d u   from the concat slot
+              load_vec<T, VEC>(e2, dyrow + dim + c, true);    // d attn from the concat slot
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              o.v[i] = rstd * (gg[k].v[i] - c2 - xh[k].v[i] * c1) + (concat ? e2.v[i] : 0.f);
+              o2.v[i] = uv[k].v[i] + (concat ? e1.v[i] : 0.f);
+            }
+            store_vec<T, VEC>(o, dattn + row * dim + c);
+            store_vec<T, VEC>(o2, du + row * dim + c);
+          }
+        }
+      }
+    }
+  }
+  if (GN) {
+    // per-head partials: reduce over the wave, then over the workgroup's waves
+    float* out_row = partial + (int64_t)blockIdx.x * 2 * heads;
+#pragma unroll
+    for (int h = 0; h < 16; ++h) {
+      if (h < heads) {
+        const float a = wave_sum(ghw[h]), c = wave_sum(ghb[h]);
+        if (lane == 0) { lds[wave * 32 + h] = a; lds[wave * 32 + 16 + h] = c; }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < heads) {
+      float a = 0.f, c = 0.f;
+      for (int w2 = 0; w2 < kNormWaves; ++w2) { a += lds[w2 * 32 + threadIdx.x]; c += lds[w2 * 32 + 16 + threadIdx.x]; }
+      out_row[threadIdx.x] = a;
+      out_row[heads + threadIdx.x] = c;
+    }
+  } else {
+    block_reduce_cols<VEC>(dw, lds, partial + (int64_t)blockIdx.x * 2 * dim, dim, nch);
+    block_reduce_cols<VEC>(db, lds, partial + (int64_t)blockIdx.x * 2 * dim + dim, dim, nch);
+  }
+}
+
+// ------------------------------------------------------------------ SiLU on a column slice
+template <typename T, bool BWD>
+__global__ void silu_kernel(const T* dout, const T* in, T* out, int64_t rows, int cols, int64_t s_dout, int64_t s_in,
+                            int64_t s_out) {
+  const int64_t n = rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i % cols);
+    const float x = (float)in[r * s_in + c];
+    const float sg = 1.0f / (1.0f + __expf(-x));
+    if (BWD) out[r * s_out + c] = (T)((float)dout[r * s_dout + c] * sg * (1.f + x * (1.f - sg)));
+    else out[r * s_out + c] = (T)(x * sg);
+  }
+}
+
+// ------------------------------------------------------------------ host-side dispatch
+static int norm_blocks(int64_t rows) {
+  int64_t b = (rows + kNormWaves - 1) / kNormWaves;
+  if (b > kMaxNormBlocks) b = kMaxNormBlocks;
+  return b < 1 ? 1 : (int)b;
+}
+
+template <typename T> static int vec_for(int dim, const void* a, const void* b2, const void* c) {
+  const int v = sizeof(T) == 2 ? 8 : 4;
+  const uintptr_t bits = (uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c;
+  return (dim % v == 0 && (bits & 15) == 0) ? v : 1;
+}
+
+static int check_dim(int dim, int vec, const char* who) {
+  if (dim <= 0) return set_error(HSTU_EINVAL, "%s: dim must be positive", who);
+  if (dim > 64 * vec * (vec == 8 ? 2 : (vec == 4 ? 4 : 8))) return set_error(HSTU_EUNSUPPORTED, "%s: dim %d exceeds the %d supported with this alignment", who, dim, 64 * vec * (vec == 8 ? 2 : (vec == 4 ? 4 : 8)));
+  return HSTU_OK;
+}
+
+template <typename T>
+static int ln_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows, int dim,
+                  float eps, hipStream_t st) {
+  const int v = vec_for<T>(dim, x, y, w) == 1 ? 1 : vec_for<T>(dim, b, nullptr, nullptr);
+  if (int e = check_dim(dim, v, "layer_norm_fwd")) return e;
+  const int nb = norm_blocks(rows);
+  if (v == 1)
+    hipLaunchKernelGGL((layer_norm_fwd_kernel<T, 1>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)x, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, dim, eps);
+  else
+    hipLaunchKernelGGL((layer_norm_fwd_kernel<T, (sizeof(T) == 2 ? 8 : 4)>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)x, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, dim, eps);
+  return check_launch("layer_norm_fwd");
+}
+
+template <typename T>
+static int ln_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx,
+                  float* dweight, float* dbias, float* partial, int64_t rows, int dim, hipStream_t st) {
+  int v = vec_for<T>(dim, dy, x, dx);
+  if (v != 1) v = vec_for<T>(dim, w, nullptr, nullptr);
+  if (int e = check_dim(dim, v, "layer_norm_bwd")) return e;
+  const int nb = norm_blocks(rows);
+  const int nch = (dim + 64 * v - 1) / (64 * v);
+  const size_t lds = (size_t)kNormWaves * nch * 64 * v * sizeof(float);
+  if (v == 1)
+    hipLaunchKernelGGL((layer_norm_bwd_kernel<T, 1>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)x, (const T*)w, mean, rstd, (T*)dx, partial, rows, dim);
+  else
+    hipLaunchKernelGGL((layer_norm_bwd_kernel<T, (sizeof(T) == 2 ? 8 : 4)>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)x, (const T*)w, mean, rstd, (T*)dx, partial, rows, dim);
+  if (int e = check_launch("layer_norm_bwd")) return e;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, partial, nb, 2 * dim, dim, dweight);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, partial + dim, nb, 2 * dim, dim, dbias);
+  return check_launch("layer_norm_bwd(reduce)");
+}
+
+template <typename T>
+static int nm_fwd(const void* attn, const void* u, const void* w, const void* b, void* y, float* mean, float* rstd,
+                  int64_t rows, int heads, int hdim, float eps, int gn, int concat, hipStream_t st) {
+  const int dim = heads * hdim;
+  int v = vec_for<T>(dim, attn, u, y);
+  if (v != 1 && !gn) v = vec_for<T>(dim, w, b, nullptr);
+  if (v != 1 && gn && hdim % v) v = 1;
+  if (int e = check_dim(dim, v, "norm_mul_fwd")) return e;
+  if (gn && heads > 16) return set_error(HSTU_EUNSUPPORTED, "norm_mul: group norm supports at most 16 heads");
+  const int nb = norm_blocks(rows);
+#define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_fwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, heads, hdim, eps, concat)
+  constexpr int VV = sizeof(T) == 2 ? 8 : 4;
+  if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
+  else { if (gn) NM_LAUNCH(VV, true); else NM_LAUNCH(VV, false); }
+#undef NM_LAUNCH
+  return check_launch("norm_mul_fwd");
+}
+
+template <typename T>
+static int nm_bwd(const void* dy, const void* attn, const void* u, const void* w, const void* b, const float* mean,
+                  const float* rstd, void* dattn, void* du, float* dweight, float* dbias, float* partial, int64_t rows,
+                  int heads, int hdim, int gn, int concat, hipStream_t st) {
+  const int dim = heads * hdim;
+  int v = vec_for<T>(dim, attn, u, dy);
+  if (v != 1) v = vec_for<T>(dim, dattn, du, nullptr);
+  if (v != 1 && !gn) v = vec_for<T>(dim, w, b, nullptr);
+  if (v != 1 && gn && hdim % v) v = 1;
+  if (int e = check_dim(dim, v, "norm_mul_bwd")) return e;
+  if (gn && heads > 16) return set_error(HSTU_EUNSUPPORTED, "norm_mul: group norm supports at most 16 heads");
+  const int nb = norm_blocks(rows);
+  const int nch = (dim + 64 * v - 1) / (64 * v);
+  const size_t lds = gn ? kNormWaves * 32 * sizeof(float) : (size_t)kNormWaves * nch * 64 * v * sizeof(float);
+#define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_bwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, mean, rstd, (T*)dattn, (T*)du, partial, rows, heads, hdim, concat)
+  constexpr int VV = sizeof(T) == 2 ? 8 : 4;
+  if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
+  else { if (gn) NM_LAUNCH(VV, true); else NM_LAUNCH(VV, false); }
+#undef NM_LAUNCH
+  if (int e = check_launch("norm_mul_bwd")) return e;
+  const int width = gn ? heads : dim;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, st, partial, nb, 2 * width, width, dweight);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, st, partial + width, nb, 2 * width, width, dbias);
+  return check_launch("norm_mul_bwd(reduce)");
+}
+
+template <typename T, bool BWD>
+static int silu_launch(const void* dout, const void* in, void* out, int64_t rows, int cols, int64_t s0, int64_t s1,
+                       int64_t s2, hipStream_t st) {
+  const int64_t n = rows * cols;
+  if (n == 0) return HSTU_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((silu_kernel<T, BWD>), dim3(blocks), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)out, rows, cols, s0, s1, s2);
+  return check_launch("silu");
+}
+
+}  // namespace hstu
+
+using namespace hstu;
+
+#define DISPATCH_DTYPE(dtype, CALL_BF16, CALL_F16, CALL_F32)                          \
+  switch (dtype) {                                                                    \
+    case HSTU_DTYPE_BF16: return CALL_BF16;                                           \
+    case HSTU_DTYPE_F16: return CALL_F16;                                             \
+    case HSTU_DTYPE_F32: return CALL_F32;                                             \
+    default: return set_error(HSTU_EINVAL, "dtype must be bf16, fp16 or fp32");       \
+  }
+
+extern "C" {
+
+size_t hstu_norm_bwd_workspace_bytes(int64_t rows, int32_t dim) {
+  (void)rows;
+  return (size_t)kMaxNormBlocks * 2 * (size_t)dim * sizeof(float);
+}
+
+int hstu_layer_norm_fwd(const void* x, const void* weight, const void* bias, void* y, float* mean, float* rstd,
+                        int64_t rows, int32_t dim, float eps, int dtype, void* stream) {
+  if (rows == 0) return HSTU_OK;
+  if (!x || !weight || !bias || !y) return set_error(HSTU_EINVAL, "layer_norm_fwd: NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DTYPE(dtype, ln_fwd<bf16_t>(x, weight, bias, y, mean, rstd, rows, dim, eps, st),
+                 ln_fwd<f16_t>(x, weight, bias, y, mean, rstd, rows, dim, eps, st),
+                 ln_fwd<float>(x, weight, bias, y, mean, rstd, rows, dim, eps, st));
+}
+
+int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight, const float* mean, const float* rstd,
+                        void* dx, float* dweight, float* dbias, float* partial_ws, int64_t rows, int32_t dim, int dtype,
+                        void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!dweight || !dbias) return set_error(HSTU_EINVAL, "layer_norm_bwd: dweight/dbias are required");
+  if (rows == 0) {
+    (void)hipMemsetAsync(dweight, 0, dim * sizeof(float), st);
+    (void)hipMemsetAsync(dbias, 0, dim * sizeof(float), st);
+    return HSTU_OK;
+  }
+  if (!dy || !x || !weight || !mean || !rstd || !dx || !partial_ws) return set_error(HSTU_EINVAL, "layer_norm_bwd: NULL tensor");
+  DISPATCH_DTYPE(dtype, ln_bwd<bf16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, st),
+                 ln_bwd<f16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, st),
+                 ln_bwd<float>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, st));
+}
+
+int hstu_norm_mul_fwd(const void* attn, const void* u, const void* weight, const void* bias, void* y, float* mean,
+                      float* rstd, int64_t rows, int32_t heads, int32_t head_dim, float eps, int group_norm,
+                      int concat_ux, int dtype, void* stream) {
+  if (rows == 0) return HSTU_OK;
+  if (!attn || !u || !weight || !bias || !y) return set_error(HSTU_EINVAL, "norm_mul_fwd: NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DTYPE(dtype, nm_fwd<bf16_t>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, st),
+                 nm_fwd<f16_t>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, st),
+                 nm_fwd<float>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, st));
+}
+
+int hstu_norm_mul_bwd(const void* dy, const void* attn, const void* u, const void* weight, const void* bias,
+                      const float* mean, const float* rstd, void* dattn, void* du, float* dweight, float* dbias,
+                      float* partial_ws, int64_t rows, int32_t heads, int32_t head_dim, int group_norm, int concat_ux,
+                      int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int width = group_norm ? heads : heads * head_dim;
+  if (!dweight || !dbias) return set_error(HSTU_EINVAL, "norm_mul_bwd: dweight/dbias are required");
+  if (rows == 0) {
+    (void)hipMemsetAsync(dweight, 0, width * sizeof(float), st);
+    (void)hipMemsetAsync(dbias, 0, width * sizeof(float), st);
+    return HSTU_OK;
+  }
+  if (!dy || !attn || !u || !weight || !bias || !mean || !rstd || !dattn || !du || !partial_ws)
+    return set_error(HSTU_EINVAL, "norm_mul_bwd: NULL tensor");
+  DISPATCH_DTYPE(dtype, nm_bwd<bf16_t>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, st),
+                 nm_bwd<f16_t>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, st),
+                 nm_bwd<float>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, st));
+}
+
+int hstu_silu_fwd(const void* in, void* out, int64_t rows, int32_t cols, int64_t in_row_stride, int64_t out_row_stride,
+                  int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DTYPE(dtype, (silu_launch<bf16_t, false>(nullptr, in, out, rows, cols, 0, in_row_stride, out_row_stride, st)),
+                 (silu_launch<f16_t, false>(nullptr, in, out, rows, cols, 0, in_row_stride, out_row_stride, st)),
+                 (silu_launch<float, false>(nullptr, in, out, rows, cols, 0, in_row_stride, out_row_stride, st)));
+}
+
+int hstu_silu_bwd(const void* dout, const void* in, void* din, int64_t rows, int32_t cols, int64_t dout_row_stride,
+                  int64_t in_row_stride, int64_t din_row_stride, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DTYPE(dtype, (silu_launch<bf16_t, true>(dout, in, din, rows, cols, dout_row_stride, in_row_stride, din_row_stride, st)),
+                 (silu_launch<f16_t, true>(dout, in, din, rows, cols, dout_row_stride, in_row_stride, din_row_stride, st)),
+                 (silu_launch<float, true>(dout, in, din, rows, cols, dout_row_stride, in_row_stride, din_row_stride, st)));
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""Data-parallel plumbing for the HSTU hot path: one process per GPU, the batch of users is
+sharded across ranks (every op on the path is per-user, so the forward needs no
+collective), and the layer-parameter gradients are summed with ONE bucketed all-reduce per
+step on RCCL over xGMI (``backend="nccl"`` under PyTorch-ROCm; ``gloo`` in CPU tests).
+
+Mirrors the role of DistributedSampler + DDP in the reference trainer
+(research/trainer/data_loader.py:39-46, research/trainer/train.py:73-78,269) without
+wrapping the model: the attention-only benchmark has no parameters and therefore no
+collective at all; the layer benchmark calls ``GradientAllReducer.reduce()`` after backward.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Tuple, Union
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from torchrun-style env; initialises the process group
+    when WORLD_SIZE > 1.  MASTER_ADDR defaults to 127.0.0.1 (container hostnames may not
+    resolve)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_users(lengths: torch.Tensor, rank: int, world_size: int, balance: str = "count") -> torch.Tensor:
+    """Indices of the users owned by ``rank``.
+
+    ``count``: contiguous equal-count slices [g*B/G, (g+1)*B/G).
+    ``work`` : greedy longest-processing-time assignment on L^2 (attention work), for
+               long-tailed length distributions; deterministic, identical on every rank.
+    """
+    B = lengths.numel()
+    if world_size == 1:
+        return torch.arange(B)
+    if balance == "count":
+        lo, hi = rank * B // world_size, (rank + 1) * B // world_size
+        return torch.arange(lo, hi)
+    if balance != "work":
+        raise ValueError(f"unknown balance mode {balance}")
+    work = lengths.to(torch.float64).cpu() ** 2
+    order = torch.argsort(work, descending=True, stable=True).tolist()
+    load = [0.0] * world_size
+    mine: List[int] = []
+    for u in order:
+        g = min(range(world_size), key=lambda r: (load[r], r))
+        load[g] += float(work[u])
+        if g == rank:
+            mine.append(u)
+    return torch.tensor(sorted(mine), dtype=torch.int64)
+
+
+def local_offsets(lengths: torch.Tensor) -> torch.Tensor:
+    """Re-based seq_offsets of a shard ([0, cumsum(lengths)], int64)."""
+    off = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=lengths.device)
+    off[1:] = torch.cumsum(lengths.to(torch.int64), 0)
+    return off
+
+
+class GradientAllReducer:
+    """Flat-bucket gradient all-reduce (sum or mean).
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU) and the in-scope parameters are
+    small (3 STU layers at D=512: 5.5 M params = 22 MB fp32), so the whole
+    gradient fits ONE bucket: a single large collective keeps every link busy and pays the
+    launch latency once.  Larger models split at ``bucket_bytes``.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.average = average
+        self.buckets: List[List[torch.nn.Parameter]] = []
+        cur: List[torch.nn.Parameter] = []
+        cur_bytes = 0
+        for p in self.params:
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype):
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+
+    def reduce(self) -> None:
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        handles = []
+        for i, bucket in enumerate(self.buckets):
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+            n = sum(g.numel() for g in grads)
+            flat = self._flat[i]
+            if flat is None or flat.numel() != n or flat.device != grads[0].device:
+                flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+                self._flat[i] = flat
+            torch.cat([g.reshape(-1) for g in grads], out=flat)
+            handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+        for work, flat, bucket in handles:
+            work.wait()
+            if self.average:
+                flat.div_(world)
+            o = 0
+            for p in bucket:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = flat[o : o + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[o : o + n].view_as(p))
+                o += n
+
+
+def max_over_ranks(value: float, device: Union[torch.device, str] = "cpu") -> float:
+    """MAX of a python float over all ranks (bench timing contract)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device: Union[torch.device, str] = "cpu") -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -1,0 +1,326 @@
+"""Tensor -> C-ABI marshalling for libhstu_hip.so.  No math here: every function packs
+pointers / strides / sizes, launches on torch's current stream, and returns torch tensors
+it allocated for the outputs."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from generative_recommenders_amd import _lib as L
+
+
+def _vp(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _aligned_rows(t: torch.Tensor) -> torch.Tensor:
+    """(rows, H, d) tensor whose last dim is contiguous and whose (row, head) vectors start
+    16-byte aligned; copies only when the layout forces it (flash_common.cpp:360-365)."""
+    es = t.element_size()
+    ok = (
+        t.stride(-1) == 1
+        and (t.stride(0) * es) % 16 == 0
+        and (t.stride(1) * es) % 16 == 0
+        and t.data_ptr() % 16 == 0
+    )
+    return t if ok else t.contiguous()
+
+
+def _idx(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype not in (torch.int32, torch.int64):
+        t = t.to(torch.int64)
+    return t.contiguous()
+
+
+def _fill_attn_params(p: L.HstuAttnParams, q, k, v, out, seq_offsets, num_targets, max_seq_len, alpha, scale,
+                      max_attn_len, contextual_seq_len, min_full_attn_seq_len, delta_q) -> None:
+    p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    p.out = _vp(out)
+    p.seq_offsets = seq_offsets.data_ptr()
+    p.num_targets = _vp(num_targets)
+    p.q_row_stride, p.q_head_stride = q.stride(0), q.stride(1)
+    p.k_row_stride, p.k_head_stride = k.stride(0), k.stride(1)
+    p.v_row_stride, p.v_head_stride = v.stride(0), v.stride(1)
+    if out is not None:
+        p.o_row_stride, p.o_head_stride = out.stride(0), out.stride(1)
+    p.batch = seq_offsets.numel() - 1
+    p.heads = q.shape[1]
+    p.dqk, p.dv = q.shape[2], v.shape[2]
+    p.max_seq_len = int(max_seq_len)
+    p.delta_q = int(delta_q)
+    p.alpha = float(alpha)
+    p.scale = float(scale)
+    p.max_attn_len = int(max_attn_len)
+    p.contextual_seq_len = int(contextual_seq_len)
+    p.min_full_attn_seq_len = int(min_full_attn_seq_len)
+    p.dtype = L.torch_dtype_code(q.dtype)
+    p.offsets_dtype = L.index_dtype_code(seq_offsets)
+    p.targets_dtype = L.index_dtype_code(num_targets) if num_targets is not None else 0
+
+
+def attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len=0,
+             contextual_seq_len=0, min_full_attn_seq_len=0, delta_q=0) -> torch.Tensor:
+    for name, t in (("q", q), ("k", k), ("v", v), ("seq_offsets", seq_offsets)):
+        L.require_gpu_tensor(t, name)
+    if not (q.dtype == k.dtype == v.dtype):
+        raise RuntimeError("q, k, v must have the same dtype")
+    q, k, v = _aligned_rows(q), _aligned_rows(k), _aligned_rows(v)
+    seq_offsets, num_targets = _idx(seq_offsets), _idx(num_targets)
+    out = torch.empty((q.shape[0], q.shape[1], v.shape[2]), dtype=q.dtype, device=q.device)
+    if q.shape[0] == 0:
+        return out
+    p = L.HstuAttnParams()
+    _fill_attn_params(p, q, k, v, out, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len,
+                      contextual_seq_len, min_full_attn_seq_len, delta_q)
+    with torch.cuda.device(q.device):
+        L.check(L.lib().hstu_attn_fwd(C.byref(p), L.current_stream_ptr(q.device)))
+    return out
+
+
+def attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len=0,
+             contextual_seq_len=0, min_full_attn_seq_len=0,
+             dq: Optional[torch.Tensor] = None, dk: Optional[torch.Tensor] = None,
+             dv: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """dq/dk/dv may be pre-allocated (possibly strided views of one fused buffer), as in
+    hstu::hstu_mha_bwd (flash_api.cpp:111-141)."""
+    for name, t in (("dout", dout), ("q", q), ("k", k), ("v", v)):
+        L.require_gpu_tensor(t, name)
+    q, k, v, dout = _aligned_rows(q), _aligned_rows(k), _aligned_rows(v), _aligned_rows(dout)
+    seq_offsets, num_targets = _idx(seq_offsets), _idx(num_targets)
+    dq = torch.empty_like(q, memory_format=torch.contiguous_format) if dq is None else dq
+    dk = torch.empty_like(k, memory_format=torch.contiguous_format) if dk is None else dk
+    dv = torch.empty_like(v, memory_format=torch.contiguous_format) if dv is None else dv
+    if q.shape[0] == 0:
+        return dq, dk, dv
+    bp = L.HstuAttnBwdParams()
+    _fill_attn_params(bp.fwd, q, k, v, None, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len,
+                      contextual_seq_len, min_full_attn_seq_len, 0)
+    bp.dout, bp.dq, bp.dk, bp.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    bp.do_row_stride, bp.do_head_stride = dout.stride(0), dout.stride(1)
+    bp.dq_row_stride, bp.dq_head_stride = dq.stride(0), dq.stride(1)
+    bp.dk_row_stride, bp.dk_head_stride = dk.stride(0), dk.stride(1)
+    bp.dv_row_stride, bp.dv_head_stride = dv.stride(0), dv.stride(1)
+    bp.total_rows = q.shape[0]
+    ws_bytes = L.lib().hstu_attn_bwd_workspace_bytes(C.byref(bp))
+    ws = None
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        bp.workspace = ws.data_ptr()
+    with torch.cuda.device(q.device):
+        L.check(L.lib().hstu_attn_bwd(C.byref(bp), L.current_stream_ptr(q.device)))
+    return dq, dk, dv
+
+
+# ----------------------------------------------------------------------------- jagged
+def complete_cumsum(lengths: torch.Tensor) -> torch.Tensor:
+    L.require_gpu_tensor(lengths, "lengths")
+    lengths = _idx(lengths)
+    out = torch.empty(lengths.numel() + 1, dtype=lengths.dtype, device=lengths.device)
+    with torch.cuda.device(lengths.device):
+        L.check(L.lib().hstu_complete_cumsum(lengths.data_ptr(), out.data_ptr(), lengths.numel(),
+                                             L.index_dtype_code(lengths), L.current_stream_ptr(lengths.device)))
+    return out
+
+
+def _pair_offsets(offsets_left, offsets_right):
+    ol, orr = _idx(offsets_left), _idx(offsets_right)
+    if ol is not None and orr is not None and ol.dtype != orr.dtype:
+        ol, orr = ol.to(torch.int64), orr.to(torch.int64)
+    ref = ol if ol is not None else orr
+    return ol, orr, L.index_dtype_code(ref), ref.numel() - 1
+
+
+def concat_2d_jagged(values_left, values_right, offsets_left, offsets_right, max_len_left, max_len_right,
+                     max_seq_len, n_prefix=0) -> torch.Tensor:
+    L.require_gpu_tensor(values_left, "values_left")
+    L.require_gpu_tensor(values_right, "values_right")
+    vl, vr = values_left.contiguous(), values_right.contiguous()
+    dim = vl.shape[1]
+    out = torch.empty((vl.shape[0] + vr.shape[0], dim), dtype=vl.dtype, device=vl.device)
+    if out.shape[0] == 0:
+        return out
+    if offsets_left is None and offsets_right is None:
+        batch, idt, ol, orr = vl.shape[0] // max_len_left, 0, None, None
+    else:
+        ol, orr, idt, batch = _pair_offsets(offsets_left, offsets_right)
+    with torch.cuda.device(vl.device):
+        L.check(L.lib().hstu_concat_2d_jagged(vl.data_ptr(), vr.data_ptr(), out.data_ptr(), _vp(ol), _vp(orr),
+                                              int(max_len_left or 0), int(max_len_right or 0), int(max_seq_len),
+                                              batch, dim, vl.element_size(), int(n_prefix), idt,
+                                              L.current_stream_ptr(vl.device)))
+    return out
+
+
+def split_2d_jagged(values, total_left, total_right, offsets_left, offsets_right, max_len_left, max_len_right,
+                    max_seq_len, n_prefix=0) -> Tuple[torch.Tensor, torch.Tensor]:
+    L.require_gpu_tensor(values, "values")
+    vals = values.contiguous()
+    dim = vals.shape[1]
+    left = torch.empty((total_left, dim), dtype=vals.dtype, device=vals.device)
+    right = torch.empty((total_right, dim), dtype=vals.dtype, device=vals.device)
+    if vals.shape[0] == 0:
+        return left, right
+    ol, orr, idt, batch = _pair_offsets(offsets_left, offsets_right)
+    with torch.cuda.device(vals.device):
+        L.check(L.lib().hstu_split_2d_jagged(vals.data_ptr(), left.data_ptr(), right.data_ptr(), _vp(ol), _vp(orr),
+                                             int(max_len_left or 0), int(max_len_right or 0), int(max_seq_len),
+                                             batch, dim, vals.element_size(), int(n_prefix), idt,
+                                             L.current_stream_ptr(vals.device)))
+    return left, right
+
+
+def jagged_to_padded_dense(values, offsets, max_len) -> torch.Tensor:
+    L.require_gpu_tensor(values, "values")
+    vals = values.contiguous()
+    offsets = _idx(offsets)
+    B = offsets.numel() - 1
+    dim = 1
+    for s_ in vals.shape[1:]:
+        dim *= s_
+    dense = torch.empty((B, max_len) + tuple(vals.shape[1:]), dtype=vals.dtype, device=vals.device)
+    if dense.numel() == 0:
+        return dense
+    with torch.cuda.device(vals.device):
+        L.check(L.lib().hstu_jagged_to_padded_dense(vals.data_ptr(), dense.data_ptr(), offsets.data_ptr(), B,
+                                                    int(max_len), dim, vals.element_size(),
+                                                    L.index_dtype_code(offsets), L.current_stream_ptr(vals.device)))
+    return dense
+
+
+def dense_to_jagged(dense, offsets, total_rows) -> torch.Tensor:
+    L.require_gpu_tensor(dense, "dense")
+    d = dense.contiguous()
+    offsets = _idx(offsets)
+    B, max_len = d.shape[0], d.shape[1]
+    dim = 1
+    for s in d.shape[2:]:
+        dim *= s
+    out = torch.zeros((total_rows,) + tuple(d.shape[2:]), dtype=d.dtype, device=d.device)
+    if out.numel() == 0 or d.numel() == 0:
+        return out
+    with torch.cuda.device(d.device):
+        L.check(L.lib().hstu_dense_to_jagged(d.data_ptr(), out.data_ptr(), offsets.data_ptr(), B, max_len, dim,
+                                             d.element_size(), L.index_dtype_code(offsets),
+                                             L.current_stream_ptr(d.device)))
+    return out
+
+
+def expand_1d_jagged_to_dense(values, offsets, max_len) -> torch.Tensor:
+    L.require_gpu_tensor(values, "values")
+    vals, offsets = values.contiguous(), _idx(offsets)
+    B = offsets.numel() - 1
+    out = torch.empty((B, max_len), dtype=vals.dtype, device=vals.device)
+    with torch.cuda.device(vals.device):
+        L.check(L.lib().hstu_expand_1d_jagged_to_dense(vals.data_ptr(), offsets.data_ptr(), out.data_ptr(), B,
+                                                       int(max_len), vals.element_size(),
+                                                       L.index_dtype_code(offsets), L.current_stream_ptr(vals.device)))
+    return out
+
+
+def concat_1d_jagged_jagged(lengths_left, values_left, lengths_right, values_right) -> torch.Tensor:
+    L.require_gpu_tensor(values_left, "values_left")
+    ol = complete_cumsum(lengths_left.to(torch.int64))
+    orr = complete_cumsum(lengths_right.to(torch.int64))
+    vl, vr = values_left.contiguous(), values_right.contiguous()
+    out = torch.empty(vl.numel() + vr.numel(), dtype=vl.dtype, device=vl.device)
+    with torch.cuda.device(vl.device):
+        L.check(L.lib().hstu_concat_1d_jagged_jagged(vl.data_ptr(), ol.data_ptr(), vr.data_ptr(), orr.data_ptr(),
+                                                     out.data_ptr(), lengths_left.numel(), vl.element_size(),
+                                                     L.HSTU_INDEX_I64, L.current_stream_ptr(vl.device)))
+    return out
+
+
+# ----------------------------------------------------------------------------- norms
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def layer_norm_fwd(x, weight, bias, eps):
+    L.require_gpu_tensor(x, "x")
+    x = x.contiguous()
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    mean, rstd = _f32(rows, x.device), _f32(rows, x.device)
+    w, b = weight.to(x.dtype).contiguous(), bias.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_layer_norm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), rows, dim, float(eps), L.torch_dtype_code(x.dtype),
+                                            L.current_stream_ptr(x.device)))
+    return y, mean, rstd
+
+
+def layer_norm_bwd(dy, x, weight, mean, rstd):
+    dy, x = dy.contiguous(), x.contiguous()
+    rows, dim = x.shape
+    dx = torch.empty_like(x)
+    dw, db = _f32(dim, x.device), _f32(dim, x.device)
+    ws = torch.empty(L.lib().hstu_norm_bwd_workspace_bytes(rows, dim), dtype=torch.uint8, device=x.device)
+    w = weight.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_layer_norm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                            ws.data_ptr(), rows, dim, L.torch_dtype_code(x.dtype),
+                                            L.current_stream_ptr(x.device)))
+    return dx, dw, db
+
+
+def norm_mul_fwd(attn, u, weight, bias, eps, num_heads, head_dim, group_norm, concat_ux):
+    L.require_gpu_tensor(attn, "attn")
+    attn, u = attn.contiguous(), u.contiguous()
+    rows, dim = attn.shape
+    y = torch.empty((rows, 3 * dim if concat_ux else dim), dtype=attn.dtype, device=attn.device)
+    ng = num_heads if group_norm else 1
+    mean, rstd = _f32(rows * ng, attn.device), _f32(rows * ng, attn.device)
+    w, b = weight.to(attn.dtype).contiguous(), bias.to(attn.dtype).contiguous()
+    with torch.cuda.device(attn.device):
+        L.check(L.lib().hstu_norm_mul_fwd(attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), rows, num_heads, head_dim, float(eps),
+                                          int(group_norm), int(concat_ux), L.torch_dtype_code(attn.dtype),
+                                          L.current_stream_ptr(attn.device)))
+    return y, mean, rstd
+
+
+def norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, num_heads, head_dim, group_norm, concat_ux):
+    dy, attn, u = dy.contiguous(), attn.contiguous(), u.contiguous()
+    rows, dim = attn.shape
+    dattn, du = torch.empty_like(attn), torch.empty_like(u)
+    width = num_heads if group_norm else dim
+    dw, db = _f32(width, attn.device), _f32(width, attn.device)
+    ws = torch.empty(L.lib().hstu_norm_bwd_workspace_bytes(rows, dim), dtype=torch.uint8, device=attn.device)
+    w, b = weight.to(attn.dtype).contiguous(), bias.to(attn.dtype).contiguous()
+    with torch.cuda.device(attn.device):
+        L.check(L.lib().hstu_norm_mul_bwd(dy.data_ptr(), attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), dattn.data_ptr(), du.data_ptr(),
+                                          dw.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, num_heads, head_dim,
+                                          int(group_norm), int(concat_ux), L.torch_dtype_code(attn.dtype),
+                                          L.current_stream_ptr(attn.device)))
+    return dattn, du, dw, db
+
+
+def silu_fwd(x: torch.Tensor) -> torch.Tensor:
+    """silu over a 2-D (possibly column-sliced) tensor -> new contiguous tensor."""
+    L.require_gpu_tensor(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_silu_fwd(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0),
+                                      out.stride(0), L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
+    return out
+
+
+def silu_bwd(dout: torch.Tensor, x: torch.Tensor, din: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """din = dout * silu'(x); ``din`` may be a column slice of a larger buffer."""
+    dout = dout if dout.stride(1) == 1 else dout.contiguous()
+    assert x.stride(1) == 1
+    if din is None:
+        din = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_silu_bwd(dout.data_ptr(), x.data_ptr(), din.data_ptr(), x.shape[0], x.shape[1],
+                                      dout.stride(0), x.stride(0), din.stride(0), L.torch_dtype_code(x.dtype),
+                                      L.current_stream_ptr(x.device)))
+    return din

@@ -1,0 +1,255 @@
+"""Drop-in for generative_recommenders/ops/hstu_compute.py: ``hstu_compute_uqvk`` (:50-89),
+``hstu_compute_output`` (:92-168), ``hstu_preprocess_and_attention`` (:171-259).
+
+The two GEMMs go to hipBLASLt via torch.addmm / torch.mm (MFMA; what the reference does on
+AMD); everything around them -- LayerNorm, SiLU(u), the jagged attention, LN/GroupNorm * u
+with the [u, attn, y] concat -- runs on the HIP kernels of libhstu_hip.so.  The two fused
+autograd nodes follow the saved-tensor / recompute contract of the reference's Triton path
+(triton_hstu_preprocess_and_attention.py:37-293, triton_hstu_linear.py:1137-1308;
+SURVEY.md App. F): results are identical whichever recompute flags are chosen.
+"""
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from generative_recommenders_amd.common import HammerKernel
+from generative_recommenders_amd.ops import _launch
+from generative_recommenders_amd.ops.hstu_attention import hstu_mha
+from generative_recommenders_amd.ops.layer_norm import layer_norm
+
+
+def hstu_compute_uqvk(
+    x: torch.Tensor,
+    norm_weight: torch.Tensor,
+    norm_bias: torch.Tensor,
+    norm_eps: float,
+    num_heads: int,
+    attn_dim: int,
+    hidden_dim: int,
+    uvqk_weight: torch.Tensor,
+    uvqk_bias: torch.Tensor,
+    kernel: HammerKernel = HammerKernel.HIP,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """LN_affine(x) @ W + b, split as [u, v, q, k], SiLU on u only."""
+    del kernel
+    normed_x = layer_norm(x, weight=norm_weight, bias=norm_bias, eps=norm_eps)
+    uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
+    u, v, q, k = torch.split(
+        uvqk, [hidden_dim * num_heads, hidden_dim * num_heads, attn_dim * num_heads, attn_dim * num_heads], dim=1
+    )
+    u = _SiluFunction.apply(u)
+    q = q.view(-1, num_heads, attn_dim)
+    k = k.view(-1, num_heads, attn_dim)
+    v = v.view(-1, num_heads, hidden_dim)
+    return u, q, k, v
+
+
+class _SiluFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _launch.silu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _launch.silu_bwd(dy, x)
+
+
+class _NormMulFunction(torch.autograd.Function):
+    """y = u * Norm(attn) (optionally [u, attn, y]); unfused-GEMM variant used when dropout is on."""
+
+    @staticmethod
+    def forward(ctx, attn, u, weight, bias, eps, num_heads, linear_dim, group_norm, concat_ux):
+        y, mean, rstd = _launch.norm_mul_fwd(attn, u, weight, bias, eps, num_heads, linear_dim, group_norm, concat_ux)
+        ctx.save_for_backward(attn, u, weight, bias, mean, rstd)
+        ctx.meta = (num_heads, linear_dim, group_norm, concat_ux)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        attn, u, weight, bias, mean, rstd = ctx.saved_tensors
+        H, Ld, gn, cat = ctx.meta
+        dattn, du, dw, db = _launch.norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, H, Ld, gn, cat)
+        return dattn, du, dw.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None
+
+
+class _ComputeOutputFunction(torch.autograd.Function):
+    """out = x + [u, attn, u*Norm(attn)] @ W_o as ONE node (HSTUComputeOutputFunction,
+    triton_hstu_linear.py:1137-1308): y is recomputed in backward unless asked otherwise."""
+
+    @staticmethod
+    def forward(ctx, attn, u, x, norm_weight, norm_bias, output_weight, eps, num_heads, linear_dim, concat_ux,
+                group_norm, recompute_y):
+        y, mean, rstd = _launch.norm_mul_fwd(attn, u, norm_weight, norm_bias, eps, num_heads, linear_dim, group_norm,
+                                             concat_ux)
+        out = torch.addmm(x, y, output_weight)
+        saved = [attn, u, norm_weight, norm_bias, mean, rstd, output_weight]
+        if not recompute_y:
+            saved.append(y)
+        ctx.save_for_backward(*saved)
+        ctx.meta = (eps, num_heads, linear_dim, concat_ux, group_norm, recompute_y)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        eps, H, Ld, cat, gn, recompute_y = ctx.meta
+        attn, u, nw, nb, mean, rstd, Wo = ctx.saved_tensors[:7]
+        if recompute_y:
+            y, _, _ = _launch.norm_mul_fwd(attn, u, nw, nb, eps, H, Ld, gn, cat)
+        else:
+            y = ctx.saved_tensors[7]
+        dout = dout.contiguous()
+        dy = torch.mm(dout, Wo.t())
+        dWo = torch.mm(y.t(), dout)
+        dattn, du, dnw, dnb = _launch.norm_mul_bwd(dy, attn, u, nw, nb, mean, rstd, H, Ld, gn, cat)
+        return dattn, du, dout, dnw.to(nw.dtype), dnb.to(nb.dtype), dWo, None, None, None, None, None, None
+
+
+def hstu_compute_output(
+    attn: torch.Tensor,
+    u: torch.Tensor,
+    x: torch.Tensor,
+    norm_weight: torch.Tensor,
+    norm_bias: torch.Tensor,
+    norm_eps: float,
+    output_weight: torch.Tensor,
+    num_heads: int,
+    linear_dim: int,
+    dropout_ratio: float,
+    training: bool,
+    concat_ux: bool,
+    group_norm: bool,
+    recompute_y_in_backward: bool,
+    kernel: HammerKernel = HammerKernel.HIP,
+) -> torch.Tensor:
+    del kernel
+    if training and dropout_ratio > 0.0:
+        # Dropout sits between the norm kernel and the GEMM; torch's Philox stream is used
+        # (the reference's in-kernel tl.rand stream is not reproducible either: SURVEY.md §2b).
+        y = _NormMulFunction.apply(attn, u, norm_weight, norm_bias, norm_eps, num_heads, linear_dim, group_norm,
+                                   concat_ux)
+        y = F.dropout(y, p=dropout_ratio, training=True)
+        return torch.addmm(x, y, output_weight)
+    return _ComputeOutputFunction.apply(attn, u, x, norm_weight, norm_bias, output_weight, norm_eps, num_heads,
+                                        linear_dim, concat_ux, group_norm, recompute_y_in_backward)
+
+
+class _PreprocessAndAttentionFunction(torch.autograd.Function):
+    """LN -> UVQK GEMM -> split -> SiLU(u) -> jagged attention as one autograd node
+    (_HSTUPreprocessAndAttentionFunction, triton_hstu_preprocess_and_attention.py:37-293).
+    q, k, v are strided VIEWS of the fused uvqk buffer (never copied); in backward the
+    attention kernel writes dq, dk, dv straight into the slices of one duvqk buffer."""
+
+    @staticmethod
+    def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, seq_offsets, num_targets, norm_eps,
+                num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
+                recompute_uvqk, recompute_normed_x):
+        normed_x, mean, rstd = _launch.layer_norm_fwd(x, norm_weight, norm_bias, norm_eps)
+        uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
+        hv, ha = hidden_dim * num_heads, attn_dim * num_heads
+        u_pre = uvqk[:, :hv]
+        v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
+        q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, num_heads, attn_dim)
+        k = uvqk[:, 2 * hv + ha :].view(-1, num_heads, attn_dim)
+        u = _launch.silu_fwd(u_pre)
+        out = _launch.attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, attn_alpha, 1.0 / max_seq_len,
+                               max_attn_len, contextual_seq_len, 0)
+        saved = [x, norm_weight, norm_bias, mean, rstd, uvqk_weight, uvqk_bias, seq_offsets]
+        ctx.has_targets = num_targets is not None
+        if ctx.has_targets:
+            saved.append(num_targets)
+        ctx.keep_normed = not recompute_normed_x
+        ctx.keep_uvqk = not recompute_uvqk
+        if ctx.keep_normed:
+            saved.append(normed_x)
+        if ctx.keep_uvqk:
+            saved.append(uvqk)
+        ctx.save_for_backward(*saved)
+        ctx.meta = (norm_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len,
+                    contextual_seq_len)
+        return u, out.view(-1, hv)
+
+    @staticmethod
+    def backward(ctx, du, dout):
+        saved = list(ctx.saved_tensors)
+        x, nw, nb, mean, rstd, W, beta, seq_offsets = saved[:8]
+        rest = saved[8:]
+        num_targets = rest.pop(0) if ctx.has_targets else None
+        normed_x = rest.pop(0) if ctx.keep_normed else None
+        uvqk = rest.pop(0) if ctx.keep_uvqk else None
+        eps, H, A, Hd, N, alpha, w, c = ctx.meta
+        if normed_x is None:
+            normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, eps)
+        if uvqk is None:
+            uvqk = torch.addmm(beta, normed_x, W)
+        hv, ha = Hd * H, A * H
+        v = uvqk[:, hv : 2 * hv].view(-1, H, Hd)
+        q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
+        k = uvqk[:, 2 * hv + ha :].view(-1, H, A)
+        duvqk = torch.empty_like(uvqk)
+        dv = duvqk[:, hv : 2 * hv].view(-1, H, Hd)
+        dq = duvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
+        dk = duvqk[:, 2 * hv + ha :].view(-1, H, A)
+        _launch.attn_bwd(dout.reshape(-1, H, Hd), q, k, v, seq_offsets, num_targets, N, alpha, 1.0 / N, w, c, 0,
+                         dq=dq, dk=dk, dv=dv)
+        _launch.silu_bwd(du, uvqk[:, :hv], din=duvqk[:, :hv])
+        d_normed = torch.mm(duvqk, W.t())
+        dW = torch.mm(normed_x.t(), duvqk)
+        dbeta = duvqk.sum(dim=0)
+        dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
+        return (dx, dnw.to(nw.dtype), dnb.to(nb.dtype), dW, dbeta.to(beta.dtype), None, None, None, None, None, None,
+                None, None, None, None, None, None)
+
+
+def hstu_preprocess_and_attention(
+    x: torch.Tensor,
+    norm_weight: torch.Tensor,
+    norm_bias: torch.Tensor,
+    norm_eps: float,
+    num_heads: int,
+    attn_dim: int,
+    hidden_dim: int,
+    uvqk_weight: torch.Tensor,
+    uvqk_bias: torch.Tensor,
+    max_seq_len: int,
+    seq_offsets: torch.Tensor,
+    attn_alpha: float,
+    causal: bool,
+    num_targets: Optional[torch.Tensor],
+    max_attn_len: int,
+    contextual_seq_len: int,
+    recompute_uvqk_in_backward: bool,
+    recompute_normed_x_in_backward: bool,
+    sort_by_length: bool,
+    prefill: bool = False,
+    kernel: HammerKernel = HammerKernel.HIP,
+) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
+    torch._assert(max_seq_len > 0, "max_seq_len must be larger than 0")
+    torch._assert(x.dim() == 2, "x must be 2-D")
+    torch._assert(x.shape[1] == uvqk_weight.shape[0], "x.shape[1] must equal uvqk_weight.shape[0]")
+    torch._assert(
+        uvqk_weight.shape[1] == 2 * num_heads * (hidden_dim + attn_dim),
+        "uvqk_weight.shape[1] must equal 2 * num_heads * (hidden_dim + attn_dim)",
+    )
+    torch._assert(causal is True, "only causal attention is supported.")
+    es = x.element_size()
+    fusable = (attn_dim * es) % 16 == 0 and (hidden_dim * es) % 16 == 0
+    if not prefill and fusable:
+        u, attn_output = _PreprocessAndAttentionFunction.apply(
+            x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, seq_offsets, num_targets, norm_eps, num_heads,
+            attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
+            recompute_uvqk_in_backward, recompute_normed_x_in_backward,
+        )
+        return u, attn_output, None, None
+    # prefill (k, v are returned for the KV cache) or head dims that need padding
+    u, q, k, v = hstu_compute_uqvk(x, norm_weight, norm_bias, norm_eps, num_heads, attn_dim, hidden_dim,
+                                   uvqk_weight, uvqk_bias)
+    attn_output = hstu_mha(
+        max_seq_len=max_seq_len, alpha=attn_alpha, q=q, k=k, v=v, seq_offsets=seq_offsets, causal=causal,
+        dropout_pr=0.0, training=False, num_targets=num_targets, max_attn_len=max_attn_len,
+        contextual_seq_len=contextual_seq_len, sort_by_length=sort_by_length,
+    ).view(-1, hidden_dim * num_heads)
+    return u, attn_output, k, v

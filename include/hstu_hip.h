@@ -1,0 +1,211 @@
+/*
+ * hstu_hip.h -- C ABI of libhstu_hip.so, the MI355X (gfx950) HSTU hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every
+ * entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/generative_recommenders).  All functions are stream-ordered
+ * (launch on `stream`, a hipStream_t passed as void*; NULL = default stream),
+ * never synchronise the host, never allocate, borrow their inputs and write only
+ * to the output / workspace pointers they are given.  Return 0 on success, a
+ * negative HSTU_E* code otherwise; hstu_last_error() holds the message (the
+ * analogue of the reference's TORCH_CHECK text, ops/cpp/hstu_attention/
+ * flash_common.cpp:339-456).
+ *
+ * Tensors are jagged: row r of user b lives at row (seq_offsets[b] + r) of a
+ * (total_rows, heads, head_dim) array whose last dimension is contiguous; row
+ * and head strides are given in ELEMENTS and are arbitrary (q/k/v may be views
+ * of one fused uvqk buffer, triton_hstu_preprocess_and_attention.py:200-252),
+ * but every (row, head) vector must start 16-byte aligned.
+ */
+#ifndef HSTU_HIP_H_
+#define HSTU_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSTU_ABI_VERSION 1
+
+enum {
+  HSTU_OK = 0,
+  HSTU_EINVAL = -1,      /* bad argument (shape, alignment, dtype) */
+  HSTU_EUNSUPPORTED = -2,/* head dim / dtype combination not instantiated */
+  HSTU_ELAUNCH = -3,     /* HIP launch error */
+};
+
+enum { HSTU_DTYPE_BF16 = 0, HSTU_DTYPE_F16 = 1, HSTU_DTYPE_F32 = 2 };
+enum { HSTU_INDEX_I32 = 0, HSTU_INDEX_I64 = 1 };
+
+/*
+ * Attention problem description, shared by forward and backward.  Models the
+ * argument list of hstu_mha (ops/hstu_attention.py:44-61) /
+ * hstu::hstu_mha_fwd|bwd (ops/cpp/hstu_attention/flash_api.cpp:275-352) and the
+ * POD role of Flash_fwd_params (ops/cpp/hstu_attention/flash.h:23-141).
+ *
+ *   P[i,j] = silu(alpha * <q_i, k_j>) * scale * M[i,j],   O = P V
+ *
+ * scale = 1/max_seq_len in the reference (pt_hstu_attention.py:151); M is the
+ * causal/target/window/contextual mask of pt_hstu_attention.py:32-84.
+ */
+typedef struct HstuAttnParams {
+  /* data */
+  const void* q;          /* (total_q_rows, H, dqk) */
+  const void* k;          /* (total_rows,   H, dqk) */
+  const void* v;          /* (total_rows,   H, dv)  */
+  void* out;              /* fwd: (total_q_rows, H, dv), written */
+  const void* seq_offsets;/* (B+1) int32|int64, device */
+  const void* num_targets;/* (B) int32|int64 or NULL */
+  int64_t q_row_stride, q_head_stride;
+  int64_t k_row_stride, k_head_stride;
+  int64_t v_row_stride, v_head_stride;
+  int64_t o_row_stride, o_head_stride;
+  /* shape */
+  int32_t batch;          /* B */
+  int32_t heads;          /* H */
+  int32_t dqk, dv;        /* head dims; multiples of 8 (16-bit) / 4 (fp32), <= 128 */
+  int32_t max_seq_len;    /* N: launch bound on per-user length (grid size) */
+  int32_t delta_q;        /* 0: q is jagged like k/v.  >0: q holds the last
+                             delta_q rows of every user, densely (B*delta_q rows):
+                             delta_hstu_mha, ops/hstu_attention.py:131-203 */
+  /* semantics */
+  float alpha;
+  float scale;            /* 1/max_seq_len of the CALLER (not necessarily 1/N above) */
+  int32_t max_attn_len;
+  int32_t contextual_seq_len;
+  int32_t min_full_attn_seq_len;
+  /* types */
+  int32_t dtype;          /* HSTU_DTYPE_* of q,k,v,out,dout,dq,dk,dv */
+  int32_t offsets_dtype;  /* HSTU_INDEX_* of seq_offsets */
+  int32_t targets_dtype;  /* HSTU_INDEX_* of num_targets */
+} HstuAttnParams;
+
+/*
+ * Backward-only additions (hstu::hstu_mha_bwd, flash_api.cpp:323-346: dq/dk/dv
+ * are PRE-ALLOCATED by the caller and may be strided views).
+ */
+typedef struct HstuAttnBwdParams {
+  HstuAttnParams fwd;     /* q,k,v,offsets,... as in forward; fwd.out unused */
+  const void* dout;       /* (total_rows, H, dv) */
+  void* dq; void* dk; void* dv;
+  int64_t do_row_stride, do_head_stride;
+  int64_t dq_row_stride, dq_head_stride;
+  int64_t dk_row_stride, dk_head_stride;
+  int64_t dv_row_stride, dv_head_stride;
+  void* workspace;        /* hstu_attn_bwd_workspace_bytes() bytes, or NULL if 0 */
+  int64_t total_rows;     /* rows of q/k/v (= seq_offsets[B]), needed to size/zero the workspace */
+} HstuAttnBwdParams;
+
+/* library identity / errors */
+int hstu_abi_version(void);
+const char* hstu_last_error(void);
+
+/* HSTU attention forward.  Replaces triton_hstu_attention_fwd
+ * (ops/triton/triton_hstu_attention.py:1767-1846), triton_cached_hstu_mha
+ * (:2095-2170, when delta_q > 0) and hstu::hstu_mha_fwd (flash_api.cpp:34-110). */
+int hstu_attn_fwd(const HstuAttnParams* p, void* stream);
+
+/* HSTU attention backward: dq, dk, dv from dout.  Replaces
+ * triton_hstu_attention_bwd (triton_hstu_attention.py:1849-1948) and
+ * hstu::hstu_mha_bwd (flash_api.cpp:111-141).  fp32 scratch is needed only when
+ * one user's keys do not fit one workgroup. */
+size_t hstu_attn_bwd_workspace_bytes(const HstuAttnBwdParams* p);
+int hstu_attn_bwd(const HstuAttnBwdParams* p, void* stream);
+
+/* out[0] = 0, out[i+1] = sum(in[0..i]); n elements in, n+1 out; dtype preserved.
+ * Replaces hstu::complete_cumsum (ops/cpp/complete_cumsum.cu:7-47) and
+ * fbgemm::asynchronous_complete_cumsum (call site modules/stu.py:97). */
+int hstu_complete_cumsum(const void* in, void* out, int64_t n, int index_dtype, void* stream);
+
+/*
+ * Row copies between jagged 2-D tensors (bit-exact, elem_bytes in {1,2,4,8};
+ * rows are `dim` elements, contiguous).  Either side may be dense: pass
+ * offsets == NULL and its fixed per-user length in max_len_*.
+ *
+ * concat: out rows of user b = [right[:n_prefix] ; left ; right[n_prefix:]]
+ * split : inverse.  n_prefix = 0 gives plain concat_2D_jagged / split_2D_jagged
+ * (ops/jagged_tensors.py:55-144, ops/triton/triton_jagged_tensors.py:31-142);
+ * n_prefix > 0 gives hstu_concat_l2_embeddings / hstu_split_l2_embeddings
+ * (ops/jagged_tensors.py:147-207).
+ */
+int hstu_concat_2d_jagged(const void* left, const void* right, void* out,
+                          const void* offsets_left, const void* offsets_right,
+                          int32_t max_len_left, int32_t max_len_right, int32_t max_seq_len,
+                          int32_t batch, int32_t dim, int32_t elem_bytes, int32_t n_prefix,
+                          int index_dtype, void* stream);
+int hstu_split_2d_jagged(const void* in, void* left, void* right,
+                         const void* offsets_left, const void* offsets_right,
+                         int32_t max_len_left, int32_t max_len_right, int32_t max_seq_len,
+                         int32_t batch, int32_t dim, int32_t elem_bytes, int32_t n_prefix,
+                         int index_dtype, void* stream);
+
+/* jagged (total, dim) <-> padded dense (batch, max_len, dim); rows >= max_len are
+ * dropped, missing rows are filled with zero bytes.  Replaces
+ * fbgemm::jagged_to_padded_dense / fbgemm::dense_to_jagged as used at
+ * ops/pytorch/pt_hstu_attention.py:97-125,167-171 and
+ * research/modeling/sequential/hstu.py:523,534. */
+int hstu_jagged_to_padded_dense(const void* values, void* dense, const void* offsets,
+                                int32_t batch, int32_t max_len, int32_t dim, int32_t elem_bytes,
+                                int index_dtype, void* stream);
+int hstu_dense_to_jagged(const void* dense, void* values, const void* offsets,
+                         int32_t batch, int32_t max_len, int32_t dim, int32_t elem_bytes,
+                         int index_dtype, void* stream);
+
+/* 1-D jagged helpers: hstu::expand_1d_jagged_to_dense
+ * (ops/cpp/expand_1d_jagged_to_dense.cu:31-103; pads with the user's LAST value,
+ * zeros if empty) and hstu::concat_1d_jagged_jagged
+ * (ops/cpp/concat_1d_jagged_jagged.cu:33-127).  elem_bytes in {4, 8}. */
+int hstu_expand_1d_jagged_to_dense(const void* values, const void* offsets, void* dense,
+                                   int32_t batch, int32_t max_len, int32_t elem_bytes,
+                                   int index_dtype, void* stream);
+int hstu_concat_1d_jagged_jagged(const void* values_left, const void* offsets_left,
+                                 const void* values_right, const void* offsets_right,
+                                 void* out, int32_t batch, int32_t elem_bytes,
+                                 int index_dtype, void* stream);
+
+/*
+ * Row-wise layer norm with affine, fp32 math (ops/layer_norm.py:46-76,
+ * ops/triton/triton_layer_norm.py:312-470).  fwd writes y and (optionally)
+ * mean / rstd (fp32, per row); bwd returns dx and fp32 dweight / dbias.
+ */
+int hstu_layer_norm_fwd(const void* x, const void* weight, const void* bias, void* y,
+                        float* mean, float* rstd, int64_t rows, int32_t dim, float eps,
+                        int dtype, void* stream);
+int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight,
+                        const float* mean, const float* rstd, void* dx,
+                        float* dweight, float* dbias, float* partial_ws,
+                        int64_t rows, int32_t dim, int dtype, void* stream);
+size_t hstu_norm_bwd_workspace_bytes(int64_t rows, int32_t dim);
+
+/*
+ * y = u * Norm(attn) with Norm = LayerNorm over the row or per-head GroupNorm,
+ * optionally written as the concatenation [u, attn, y]  (rows, 3*dim).
+ * Replaces _ln_mul_dropout_fwd/_bwd and _group_norm_mul_dropout_fwd/_bwd
+ * (ops/triton/triton_hstu_linear.py:48-337,570-1036); dropout is not fused
+ * (the reference's Philox stream is not reproducible).
+ */
+int hstu_norm_mul_fwd(const void* attn, const void* u, const void* weight, const void* bias,
+                      void* y, float* mean, float* rstd, int64_t rows, int32_t heads,
+                      int32_t head_dim, float eps, int group_norm, int concat_ux,
+                      int dtype, void* stream);
+int hstu_norm_mul_bwd(const void* dy, const void* attn, const void* u, const void* weight,
+                      const void* bias, const float* mean, const float* rstd,
+                      void* dattn, void* du, float* dweight, float* dbias, float* partial_ws,
+                      int64_t rows, int32_t heads, int32_t head_dim, int group_norm,
+                      int concat_ux, int dtype, void* stream);
+
+/* u = silu(u) in place on the leading `u_cols` columns of each row of a
+ * (rows, row_stride) matrix, and its backward (du *= silu'(u_pre)); the SiLU-on-u
+ * epilogue of hstu_compute_uqvk (ops/hstu_compute.py:85). */
+int hstu_silu_fwd(const void* in, void* out, int64_t rows, int32_t cols,
+                  int64_t in_row_stride, int64_t out_row_stride, int dtype, void* stream);
+int hstu_silu_bwd(const void* dout, const void* in, void* din, int64_t rows, int32_t cols,
+                  int64_t dout_row_stride, int64_t in_row_stride, int64_t din_row_stride,
+                  int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSTU_HIP_H_ */

@@ -1,0 +1,58 @@
+// Test-only probes of the gfx950 facts the attention kernels rely on (MFMA fragment
+// layouts, ds_read_b64_tr_b16 semantics).  Built into tests/probe/libhstu_probe.so by
+// __graft_entry__.build(); never linked into the product library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// C = A(32x16) * B(16x32), operands given densely in global memory (bf16 as uint16 bits).
+// Lane l loads A[l&31][8*(l>>5) + j] and B[8*(l>>5) + j][l&31]; writes its 16 accumulators.
+__global__ void probe_mfma_bf16(const uint16_t* A, const uint16_t* B, float* Cregs) {
+  const int l = threadIdx.x;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    a[j] = __builtin_bit_cast(__bf16, A[(l & 31) * 16 + 8 * (l >> 5) + j]);
+    b[j] = __builtin_bit_cast(__bf16, B[(8 * (l >> 5) + j) * 32 + (l & 31)]);
+  }
+  f32x16 c = {0};
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) Cregs[l * 16 + r] = c[r];
+}
+
+// fp32 32x32x2: lane l supplies A[l&31][l>>5], B[l>>5][l&31]
+__global__ void probe_mfma_f32(const float* A, const float* B, float* Cregs) {
+  const int l = threadIdx.x;
+  f32x16 c = {0};
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(l & 31) * 2 + (l >> 5)], B[(l >> 5) * 32 + (l & 31)], c, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) Cregs[l * 16 + r] = c[r];
+}
+
+// LDS holds lds[i] = i (int16).  Every lane reads with ds_read_b64_tr_b16 from the byte
+// address addr[l]; out[l*4 + j] = the 4 values it received.
+__global__ void probe_tr_read(const int* addr, int16_t* out) {
+  __shared__ __attribute__((aligned(16))) int16_t lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (int16_t)i;
+  __syncthreads();
+  const int l = threadIdx.x;
+  s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)((char*)lds + addr[l]));
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = t[j];
+}
+
+extern "C" {
+int probe_run_mfma_bf16(const void* A, const void* B, void* C, void* stream) {
+  hipLaunchKernelGGL(probe_mfma_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (float*)C);
+  return (int)hipGetLastError();
+}
+int probe_run_mfma_f32(const void* A, const void* B, void* C, void* stream) {
+  hipLaunchKernelGGL(probe_mfma_f32, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)A, (const float*)B, (float*)C);
+  return (int)hipGetLastError();
+}
+int probe_run_tr_read(const void* addr, void* out, void* stream) {
+  hipLaunchKernelGGL(probe_tr_read, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)addr, (int16_t*)out);
+  return (int)hipGetLastError();
+}
+}

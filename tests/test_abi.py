@@ -1,0 +1,162 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds/loads, exports every symbol
+include/hstu_hip.h declares, the ctypes mirrors of the parameter structs have the C layout,
+and the host-side API raises the reference's errors.  No kernel is launched."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hstu_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hstu_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from generative_recommenders_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_header_symbols_all_exported(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), f"libhstu_hip.so does not export {name}"
+
+
+def test_ctypes_signature_table_covers_header():
+    from generative_recommenders_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == _declared_symbols()
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.hstu_abi_version() == 1
+    assert isinstance(lib.hstu_last_error(), bytes)
+
+
+def test_struct_layout_matches_c():
+    from generative_recommenders_amd import _lib
+
+    prog = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "hstu_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(HstuAttnParams), offsetof(HstuAttnParams, batch),
+         offsetof(HstuAttnParams, alpha), offsetof(HstuAttnParams, dtype), sizeof(HstuAttnBwdParams),
+         offsetof(HstuAttnBwdParams, dout), offsetof(HstuAttnBwdParams, workspace),
+         offsetof(HstuAttnBwdParams, total_rows));
+  return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "layout.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "layout")
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        got = [int(x) for x in subprocess.check_output([exe]).split()]
+    P, BP = _lib.HstuAttnParams, _lib.HstuAttnBwdParams
+    exp = [C.sizeof(P), P.batch.offset, P.alpha.offset, P.dtype.offset, C.sizeof(BP), BP.dout.offset,
+           BP.workspace.offset, BP.total_rows.offset]
+    assert got == exp
+
+
+def test_validation_errors_without_gpu(lib):
+    """Argument validation happens before any launch, so it is testable on CPU."""
+    from generative_recommenders_amd import _lib
+
+    p = _lib.HstuAttnParams()
+    assert lib.hstu_attn_fwd(C.byref(p), None) == -1
+    assert b"non-NULL" in lib.hstu_last_error()
+    buf = (C.c_char * 256)()
+    addr = (C.addressof(buf) + 15) & ~15
+    p.q = p.k = p.v = p.out = p.seq_offsets = addr
+    p.batch, p.heads, p.max_seq_len, p.dqk, p.dv = 1, 1, 0, 32, 32
+    assert lib.hstu_attn_fwd(C.byref(p), None) == -1
+    assert b"max_seq_len must be larger than 0" in lib.hstu_last_error()
+    p.max_seq_len = 8
+    p.dqk = 12
+    assert lib.hstu_attn_fwd(C.byref(p), None) == -1 and b"multiples of 8" in lib.hstu_last_error()
+    p.dqk = p.dv = 256
+    p.q_row_stride = p.k_row_stride = p.v_row_stride = p.o_row_stride = 256
+    p.q_head_stride = p.k_head_stride = p.v_head_stride = p.o_head_stride = 256
+    assert lib.hstu_attn_fwd(C.byref(p), None) == -2 and b"not instantiated" in lib.hstu_last_error()
+    assert lib.hstu_split_2d_jagged(None, None, None, None, None, 0, 0, 0, 1, 1, 4, 0, 0, None) == -1
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from generative_recommenders_amd.ops.hstu_attention import delta_hstu_mha, hstu_mha
+    from generative_recommenders_amd.ops.jagged_tensors import asynchronous_complete_cumsum, concat_2D_jagged
+    from generative_recommenders_amd.ops.layer_norm import layer_norm
+
+    q = torch.zeros(4, 2, 32, dtype=torch.bfloat16)
+    off = torch.tensor([0, 4])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hstu_mha(4, 1.0, q, q, q, off)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        delta_hstu_mha(4, 1.0, q, q, q, off)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        asynchronous_complete_cumsum(torch.tensor([1, 2]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        concat_2D_jagged(8, torch.zeros(4, 3), torch.zeros(4, 3), 4, 4, off, off)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer_norm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 1e-6)
+
+
+def test_reference_assert_messages():
+    from generative_recommenders_amd.ops.hstu_attention import hstu_mha
+    from generative_recommenders_amd.ops.jagged_tensors import split_2D_jagged
+
+    q = torch.zeros(4, 2, 32)
+    off = torch.tensor([0, 4])
+    with pytest.raises(Exception, match="max_seq_len must be larger than 0"):
+        hstu_mha(0, 1.0, q, q, q, off)
+    with pytest.raises(Exception, match="k must be the same shape as q"):
+        hstu_mha(4, 1.0, q, q[:, :1], q, off)
+    with pytest.raises(Exception, match="only support causal"):
+        hstu_mha(4, 1.0, q, q, q, off, causal=False)
+    with pytest.raises(Exception, match="cannot be None at the same time"):
+        split_2D_jagged(8, torch.zeros(4, 3))
+
+
+def test_missing_library_raises(monkeypatch):
+    from generative_recommenders_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhstu_hip.so")
+    with pytest.raises(_lib.HstuLibraryError, match="no CPU / PyTorch fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "generative_recommenders_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text, f"{f} mentions the oracle"
+
+
+def test_module_state_dict_names_match_reference():
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig
+
+    layer = STULayer(STULayerConfig(embedding_dim=16, num_heads=2, hidden_dim=8, attention_dim=8, use_group_norm=True))
+    assert sorted(layer.state_dict()) == sorted([
+        "_uvqk_weight", "_uvqk_beta", "_input_norm_weight", "_input_norm_bias", "_output_weight",
+        "_output_norm_weight", "_output_norm_bias"])
+    assert layer._uvqk_weight.shape == (16, 64) and layer._output_weight.shape == (48, 16)
+    assert layer._output_norm_weight.shape == (2,)

@@ -1,0 +1,224 @@
+"""GPU tests of the row kernels and the fused autograd nodes around the projections
+(layer norm, SiLU, LN/GroupNorm * u with concat, hstu_compute_uqvk / hstu_compute_output /
+hstu_preprocess_and_attention, STULayer / STUStack) against the reference's golden vectors
+and the numpy oracle.  fp32 runs use element-wise rtol 1e-3; TF32 does not exist on gfx950
+(torch.mm on fp32 is exact fp32), so the fp32 GEMMs are held to the same bar."""
+
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_cases
+from oracle import hstu_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, ref, rtol=1e-3, atol_scale=2e-5, what=""):
+    g = got.detach().float().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert g.shape == ref.shape, f"{what}: {g.shape} vs {ref.shape}"
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(g - ref)
+    bad = err > rtol * np.abs(ref) + atol_scale * scale
+    assert not bad.any(), f"{what}: {bad.sum()}/{bad.size} out of tolerance, max err {err.max():.3e}, scale {scale:.3e}"
+
+
+def _t(x, dtype=torch.float32, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV).to(dtype)
+    return t.requires_grad_() if grad else t
+
+
+def _compute(name):
+    for c in load_cases("compute.npz"):
+        if str(c["name"]) == name:
+            return c
+    raise KeyError(name)
+
+
+def test_layer_norm_golden_and_bwd():
+    from generative_recommenders_amd.ops.layer_norm import layer_norm
+
+    c = _compute("ln")
+    x, w, b = _t(c["x"], grad=True), _t(c["w"], grad=True), _t(c["b"], grad=True)
+    y = layer_norm(x, w, b, float(c["eps"]))
+    _close(y, c["y"], what="ln y")
+    g = torch.randn_like(y)
+    y.backward(g)
+    dx, dw, db = O.layer_norm_bwd(g.cpu().numpy(), c["x"], c["w"], float(c["eps"]))
+    _close(x.grad, dx, what="ln dx")
+    _close(w.grad, dw, what="ln dw")
+    _close(b.grad, db, what="ln db")
+
+
+@pytest.mark.parametrize("rows,dim,dtype", [(0, 64, torch.float32), (1, 32, torch.float32), (1000, 512, torch.bfloat16),
+                                            (777, 100, torch.float32), (300, 37, torch.bfloat16), (64, 1024, torch.float16),
+                                            (5000, 512, torch.float32)])
+def test_layer_norm_sweep(rows, dim, dtype):
+    """N in [0, 10000], arbitrary D (ops/tests/layer_norm_test.py:62-80)."""
+    from generative_recommenders_amd.ops.layer_norm import layer_norm
+
+    g = torch.Generator().manual_seed(rows + dim)
+    x = torch.randn(rows, dim, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(dim, generator=g)).to(dtype)
+    xd, wd, bd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = layer_norm(xd, wd, bd, 1e-6)
+    assert y.shape == (rows, dim)
+    if rows == 0:
+        return
+    ref = O.layer_norm_fwd(x.double().numpy(), w.double().numpy(), b.double().numpy(), 1e-6)
+    tol = dict(rtol=1e-3, atol_scale=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol_scale=4e-3)
+    _close(y, ref, what="y", **tol)
+    gy = torch.randn(rows, dim, generator=g).to(dtype)
+    y.backward(gy.to(DEV))
+    dx, dw, db = O.layer_norm_bwd(gy.double().numpy(), x.double().numpy(), w.double().numpy(), 1e-6)
+    _close(xd.grad, dx, what="dx", **tol)
+    wt = dict(rtol=1e-3, atol_scale=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol_scale=1e-2)
+    _close(wd.grad, dw, what="dw", **wt)
+    _close(bd.grad, db, what="db", **wt)
+
+
+def test_uvqk_golden_fwd_bwd():
+    from generative_recommenders_amd.ops.hstu_compute import hstu_compute_uqvk
+
+    c = _compute("uvqk")
+    x, nw, nb = _t(c["x"], grad=True), _t(c["nw"], grad=True), _t(c["nb"], grad=True)
+    W, beta = _t(c["W"], grad=True), _t(c["beta"], grad=True)
+    u, q, k, v = hstu_compute_uqvk(x, nw, nb, 1e-6, int(c["H"]), int(c["A"]), int(c["Hd"]), W, beta)
+    for got, name in ((u, "u"), (q, "q"), (k, "k"), (v, "v")):
+        _close(got, c[name], what=name)
+    loss = (u * _t(c["gu"])).sum() + (q * _t(c["gq"])).sum() + (k * _t(c["gk"])).sum() + (v * _t(c["gv"])).sum()
+    loss.backward()
+    _close(x.grad, c["dx"], what="dx", atol_scale=1e-4)
+    _close(nw.grad, c["dnw"], what="dnw", atol_scale=1e-4)
+    _close(nb.grad, c["dnb"], what="dnb", atol_scale=1e-4)
+    _close(W.grad, c["dW"], what="dW", atol_scale=1e-4)
+    _close(beta.grad, c["dbeta"], what="dbeta", atol_scale=1e-4)
+
+
+@pytest.mark.parametrize("name", ["out_ln", "out_ln_cat", "out_gn_cat"])
+@pytest.mark.parametrize("recompute_y", [False, True])
+def test_compute_output_golden_fwd_bwd(name, recompute_y):
+    from generative_recommenders_amd.ops.hstu_compute import hstu_compute_output
+
+    c = _compute(name)
+    attn, u, x = _t(c["attn"], grad=True), _t(c["u"], grad=True), _t(c["x"], grad=True)
+    nw, nb, Wo = _t(c["nw"], grad=True), _t(c["nb"], grad=True), _t(c["Wo"], grad=True)
+    y = hstu_compute_output(attn=attn, u=u, x=x, norm_weight=nw, norm_bias=nb, norm_eps=1e-6, output_weight=Wo,
+                            num_heads=int(c["H"]), linear_dim=int(c["Ld"]), dropout_ratio=0.0, training=False,
+                            concat_ux=bool(c["cat"]), group_norm=bool(c["gn"]), recompute_y_in_backward=recompute_y)
+    _close(y, c["y"], what="y")
+    y.backward(_t(c["gy"]))
+    for got, name2 in ((attn.grad, "dattn"), (u.grad, "du"), (x.grad, "dx"), (nw.grad, "dnw"), (nb.grad, "dnb"),
+                       (Wo.grad, "dWo")):
+        _close(got, c[name2], what=name2, atol_scale=1e-4)
+
+
+def test_compute_output_shape_of_reference_test_bf16():
+    """N=1000 rows, H=4, linear_dim=128, D=128, group norm + concat (ops/tests/hstu_compute_test.py:36-66)."""
+    from generative_recommenders_amd.ops.hstu_compute import hstu_compute_output
+
+    g = torch.Generator().manual_seed(3)
+    N, H, Ld, D = 1000, 4, 128, 128
+    attn = torch.randn(N, H * Ld, generator=g).bfloat16()
+    u = torch.randn(N, H * Ld, generator=g).bfloat16()
+    x = torch.randn(N, D, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).bfloat16()
+    nb = (0.1 * torch.randn(H, generator=g)).bfloat16()
+    Wo = (0.05 * torch.randn(3 * H * Ld, D, generator=g)).bfloat16()
+    y = hstu_compute_output(attn=attn.to(DEV), u=u.to(DEV), x=x.to(DEV), norm_weight=nw.to(DEV), norm_bias=nb.to(DEV),
+                            norm_eps=1e-6, output_weight=Wo.to(DEV), num_heads=H, linear_dim=Ld, dropout_ratio=0.0,
+                            training=False, concat_ux=True, group_norm=True, recompute_y_in_backward=True)
+    ref = O.hstu_compute_output(attn.double().numpy(), u.double().numpy(), x.double().numpy(), nw.double().numpy(),
+                                nb.double().numpy(), 1e-6, Wo.double().numpy(), H, Ld, True, True)
+    _close(y, ref, rtol=3e-2, atol_scale=1e-2, what="bf16 output")
+
+
+def _load_stack(c, dtype=torch.float32, **cfg_over):
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig, STUStack
+
+    D, H, A, Hd = int(c["D"]), int(c["H"]), int(c["A"]), int(c["Hd"])
+    layers = []
+    for gn in (False, True):
+        cfg = dict(embedding_dim=D, num_heads=H, hidden_dim=Hd, attention_dim=A, output_dropout_ratio=0.0,
+                   causal=True, target_aware=True, max_attn_len=None, attn_alpha=None, use_group_norm=gn,
+                   recompute_normed_x=True, recompute_uvqk=True, recompute_y=True, sort_by_length=True,
+                   contextual_seq_len=0)
+        cfg.update(cfg_over)
+        layers.append(STULayer(STULayerConfig(**cfg)))
+    stack = STUStack(layers)
+    sd = {k[2:]: torch.from_numpy(v) for k, v in c.items() if k.startswith("p:")}
+    stack.load_state_dict(sd)  # reference parameter names must load unchanged
+    return stack.to(DEV).to(dtype)
+
+
+@pytest.mark.parametrize("flags", [(True, True, True), (False, False, False), (True, False, True), (False, True, False)])
+def test_stu_stack_golden_fwd_bwd(flags):
+    """2-layer STUStack (LayerNorm layer + GroupNorm layer) vs the reference's PYTORCH-kernel
+    stack on identical parameters and inputs; all recompute-flag combinations must agree
+    (modules/tests/stu_test.py:48-72)."""
+    c = load_cases("stu.npz")[0]
+    stack = _load_stack(c, recompute_normed_x=flags[0], recompute_uvqk=flags[1], recompute_y=flags[2])
+    x = _t(c["x"], grad=True)
+    y = stack(x=x, x_lengths=torch.from_numpy(c["lengths"]).to(DEV), x_offsets=torch.from_numpy(c["offsets"]).to(DEV),
+              max_seq_len=int(c["N"]), num_targets=torch.from_numpy(c["num_targets"]).to(DEV))
+    _close(y, c["y"], what="stack y", atol_scale=1e-4)
+    y.backward(_t(c["gy"]))
+    _close(x.grad, c["dx"], what="stack dx", atol_scale=2e-4)
+    for name, p in stack.named_parameters():
+        _close(p.grad, c["g:" + name], what="grad " + name, rtol=2e-3, atol_scale=3e-4)
+
+
+def test_stu_cached_forward_equals_full_forward():
+    """prefill + cached_forward == full forward on the delta rows (modules/tests/stu_test.py:341-457)."""
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig, STUStack
+    from generative_recommenders_amd.ops.jagged_tensors import split_2D_jagged
+
+    torch.manual_seed(0)
+    D, H, A, Hd, delta = 64, 2, 32, 32, 8
+    layers = [STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=Hd, attention_dim=A,
+                                      output_dropout_ratio=0.0, target_aware=True, use_group_norm=bool(i)),
+                       is_inference=True) for i in range(2)]
+    stack = STUStack(layers, is_inference=True).to(DEV).eval()
+    B = 5
+    g = torch.Generator().manual_seed(1)
+    prime = torch.randint(5, 60, (B,), generator=g)
+    lengths = prime + delta
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lengths, 0)
+    N = int(lengths.max())
+    x = torch.randn(int(off[-1]), D, generator=g).to(DEV)
+    nt = torch.randint(1, delta + 1, (B,), generator=g).to(DEV)
+    offd, lend, primed = off.to(DEV), lengths.to(DEV), prime.to(DEV)
+    with torch.no_grad():
+        full = stack(x=x, x_lengths=lend, x_offsets=offd, max_seq_len=N, num_targets=nt)
+        # prefill on the prime part only, caching all of it
+        prime_off = torch.zeros(B + 1, dtype=torch.int64, device=DEV)
+        prime_off[1:] = torch.cumsum(primed, 0)
+        delta_off = delta * torch.arange(B + 1, device=DEV)
+        prime_x, delta_x = split_2D_jagged(N, x, None, None, None, delta, prime_off, None)
+        stack(x=prime_x, x_lengths=primed, x_offsets=prime_off, max_seq_len=int(prime.max()),
+              num_targets=torch.zeros_like(nt), kv_caching_lengths=primed)
+        inc = stack.cached_forward(delta_x=delta_x, num_targets=nt)
+        _, full_tail = split_2D_jagged(N, full, None, None, None, delta, prime_off, None)
+    del delta_off
+    torch.testing.assert_close(inc, full_tail, rtol=1e-4, atol=1e-5)
+
+
+def test_silu_matches_torch():
+    from generative_recommenders_amd.ops import _launch
+
+    x = torch.randn(100, 96, device=DEV)
+    sl = x[:, 16:80]
+    y = _launch.silu_fwd(sl)
+    torch.testing.assert_close(y, torch.nn.functional.silu(sl), rtol=1e-5, atol=1e-6)
+    g = torch.randn_like(y)
+    ref = torch.autograd.grad(torch.nn.functional.silu(sl.clone().requires_grad_()), [], allow_unused=True) if False else None
+    del ref
+    s = sl.clone().requires_grad_()
+    torch.nn.functional.silu(s).backward(g)
+    torch.testing.assert_close(_launch.silu_bwd(g, sl), s.grad, rtol=1e-5, atol=1e-6)

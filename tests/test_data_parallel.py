@@ -1,0 +1,64 @@
+"""CPU tests of the multi-GPU path: world_size-2 gloo process group, user sharding and the
+bucketed gradient all-reduce (the N>1 path of bench.py; RCCL on the GPU box)."""
+
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from generative_recommenders_amd import data_parallel as dp
+
+    r, lr, w = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)  # identical replicas
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+    lengths = torch.tensor([5, 1, 9, 3, 7, 2, 8, 4])
+    mine = dp.shard_users(lengths, rank, world)
+    g = torch.Generator().manual_seed(123)
+    data = torch.randn(8, 8, generator=g)
+    loss = model(data[mine]).pow(2).sum()
+    loss.backward()
+    red = dp.GradientAllReducer(model.parameters(), bucket_bytes=256, average=False)
+    assert len(red.buckets) > 1
+    red.reduce()
+    # reference: single-process gradient over the whole batch
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+    ref(data).pow(2).sum().backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+    assert dp.max_over_ranks(float(rank)) == float(world - 1)
+    assert dp.sum_over_ranks(1.0) == float(world)
+    dist.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_shard_and_allreduce(tmp_path):
+    port = 29600 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_shard_users_partitions():
+    from generative_recommenders_amd import data_parallel as dp
+
+    lengths = torch.randint(1, 200, (37,))
+    for mode in ("count", "work"):
+        seen = torch.cat([dp.shard_users(lengths, r, 4, mode) for r in range(4)])
+        assert sorted(seen.tolist()) == list(range(37))
+    # work balancing: L^2 loads within 25 % of each other on a long-tailed distribution
+    lengths = torch.cat([torch.full((4,), 200), torch.randint(1, 30, (60,))])
+    loads = [float((lengths[dp.shard_users(lengths, r, 4, "work")].double() ** 2).sum()) for r in range(4)]
+    assert max(loads) / min(loads) < 1.25
+    off = dp.local_offsets(torch.tensor([3, 0, 2]))
+    assert off.tolist() == [0, 3, 3, 5]
