@@ -173,7 +173,8 @@ def cpu_baseline(args):
     the host cores, fp32, on a bounded sample of the same workload."""
     from oracle.dense_torch import dense_hstu_mha
 
-    cores = len(os.sched_getaffinity(0))
+    # more threads than this only add synchronisation cost on a (256, 4, 200, 200) problem
+    cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
     torch.set_num_threads(cores)
     N, H, d = args.max_seq_len, args.heads, args.head_dim
     B = args.cpu_users
@@ -187,7 +188,7 @@ def cpu_baseline(args):
     v = torch.empty(L, H, d).uniform_(-0.01, 0.01, generator=gen).requires_grad_()
     do = torch.randn(L, H, d, generator=gen)
     times = []
-    for i in range(4):
+    for i in range(3):
         t0 = time.perf_counter()
         out = dense_hstu_mha(N, d**-0.5, q, k, v, off)
         out.backward(do)
@@ -195,7 +196,7 @@ def cpu_baseline(args):
         q.grad = k.grad = v.grad = None
     med = statistics.median(times[1:])
     return dict(value=B / med, unit="user-seqs/s", cores=cores, kind="port",
-                sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of 3 after 1 warm-up "
+                sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of 2 after 1 warm-up "
                        f"({med * 1e3:.0f} ms each); oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
 
 
@@ -211,7 +212,8 @@ def main():
     ap.add_argument("--head-dim", type=int, default=128)
     ap.add_argument("--layer-users-per-gpu", type=int, default=1024)
     ap.add_argument("--layer-steps", type=int, default=10)
-    ap.add_argument("--cpu-users", type=int, default=256)
+    ap.add_argument("--cpu-users", type=int, default=128)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-layer", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()

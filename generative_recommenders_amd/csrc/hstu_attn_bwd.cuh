@@ -199,17 +199,27 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         dp = E::mma(a, bb, dp);
       }
       // C layout: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf
+      // P' = silu(x), dS' = dP silu'(x) with x = alpha S; scale and alpha are applied in fp32
+      // to the accumulators at the very end (dV *= scale; dK, dQ *= scale * alpha)
       Frag pb[2], dsb[2];
+      if (mc.pair_fully_valid(i0, 32, k0w, 32)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-        const float x = s[r] * p.alpha;
-        const float sg = fast_sigmoid(x);
-        const bool ok = key_ok && qi < len && mc.valid(qi, key);
-        const float pv = ok ? x * sg * p.scale : 0.f;
-        const float dsv = ok ? dp[r] * sg * (1.f + x * (1.f - sg)) * ds_scale : 0.f;
-        E::set(pb[r >> 3], r & 7, pv);
-        E::set(dsb[r >> 3], r & 7, dsv);
+        for (int r = 0; r < 16; ++r) {
+          const float x = s[r] * p.alpha;
+          const float sg = fast_sigmoid(x);
+          E::set(pb[r >> 3], r & 7, x * sg);
+          E::set(dsb[r >> 3], r & 7, dp[r] * sg * (1.f + x * (1.f - sg)));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          const float x = s[r] * p.alpha;
+          const float sg = fast_sigmoid(x);
+          const bool ok = key_ok && qi < len && mc.valid(qi, key);
+          E::set(pb[r >> 3], r & 7, ok ? x * sg : 0.f);
+          E::set(dsb[r >> 3], r & 7, ok ? dp[r] * sg * (1.f + x * (1.f - sg)) : 0.f);
+        }
       }
       // dV_w^T[dv][key] += dO_i^T[dv][q] P[q][key]
 #pragma unroll
@@ -277,14 +287,16 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
             const int d0 = 32 * wave + 8 * rq + 4 * hf;
-            if (d0 < p.dqk) store4<T>(dqrow, d0, acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+            if (d0 < p.dqk)
+              store4<T>(dqrow, d0, acc[4 * rq] * ds_scale, acc[4 * rq + 1] * ds_scale, acc[4 * rq + 2] * ds_scale,
+                        acc[4 * rq + 3] * ds_scale);
           }
         } else {
           float* arow = dq_accum + ((off0 + qrow) * p.heads + hd) * (int64_t)p.dqk;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int d = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (d < p.dqk) atomicAdd(arow + d, acc[r]);
+            if (d < p.dqk) atomicAdd(arow + d, acc[r] * ds_scale);
           }
         }
       }
@@ -303,7 +315,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
       for (int rq = 0; rq < 4; ++rq) {
         const int d0 = 32 * d + 8 * rq + 4 * hf;
         if (d0 < p.dqk)
-          store4<T>(dkrow, d0, dk_acc[d][4 * rq], dk_acc[d][4 * rq + 1], dk_acc[d][4 * rq + 2], dk_acc[d][4 * rq + 3]);
+          store4<T>(dkrow, d0, dk_acc[d][4 * rq] * ds_scale, dk_acc[d][4 * rq + 1] * ds_scale, dk_acc[d][4 * rq + 2] * ds_scale,
+                    dk_acc[d][4 * rq + 3] * ds_scale);
       }
 #pragma unroll
     for (int d = 0; d < C::DBV; ++d)
@@ -311,7 +324,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
       for (int rq = 0; rq < 4; ++rq) {
         const int d0 = 32 * d + 8 * rq + 4 * hf;
         if (d0 < p.dv)
-          store4<T>(dvrow, d0, dv_acc[d][4 * rq], dv_acc[d][4 * rq + 1], dv_acc[d][4 * rq + 2], dv_acc[d][4 * rq + 3]);
+          store4<T>(dvrow, d0, dv_acc[d][4 * rq] * p.scale, dv_acc[d][4 * rq + 1] * p.scale, dv_acc[d][4 * rq + 2] * p.scale,
+                    dv_acc[d][4 * rq + 3] * p.scale);
       }
   }
 }

@@ -200,14 +200,23 @@ __global__ __launch_bounds__(kFwdThreads) void hstu_attn_fwd_kernel(const HstuAt
         Frag a = lds_row_frag<T, C::UPR_K>(Kt, n32, hf * (DQK / 2) + kg * 8);
         s = E::mma(a, qf[kg], s);
       }
+      // P' = silu(alpha S) [* mask]; the 1/N scale is applied once, in fp32, in the epilogue
+      // (keeps P' in the normal range of fp16/bf16 and saves a multiply per element)
       Frag pb[2];
+      if (mc.pair_fully_valid(r0 + i_shift, 32, j0, 32)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-        const float x = s[r] * p.alpha;
-        const float pv = x * fast_sigmoid(x) * p.scale;
-        const bool ok = row_ok && key < len && mc.valid(qi, key);
-        E::set(pb[r >> 3], r & 7, ok ? pv : 0.f);
+        for (int r = 0; r < 16; ++r) {
+          const float x = s[r] * p.alpha;
+          E::set(pb[r >> 3], r & 7, x * fast_sigmoid(x));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          const float x = s[r] * p.alpha;
+          const bool ok = row_ok && key < len && mc.valid(qi, key);
+          E::set(pb[r >> 3], r & 7, ok ? x * fast_sigmoid(x) : 0.f);
+        }
       }
 #pragma unroll
       for (int d = 0; d < C::DB; ++d) {
@@ -234,7 +243,9 @@ __global__ __launch_bounds__(kFwdThreads) void hstu_attn_fwd_kernel(const HstuAt
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int d0 = 32 * d + 8 * rq + 4 * hf;
-        if (d0 < p.dv) store4<T>(orow, d0, oacc[d][4 * rq], oacc[d][4 * rq + 1], oacc[d][4 * rq + 2], oacc[d][4 * rq + 3]);
+        if (d0 < p.dv)
+          store4<T>(orow, d0, oacc[d][4 * rq] * p.scale, oacc[d][4 * rq + 1] * p.scale, oacc[d][4 * rq + 2] * p.scale,
+                    oacc[d][4 * rq + 3] * p.scale);
       }
     }
   }

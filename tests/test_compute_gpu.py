@@ -174,39 +174,37 @@ def test_stu_stack_golden_fwd_bwd(flags):
 
 
 def test_stu_cached_forward_equals_full_forward():
-    """prefill + cached_forward == full forward on the delta rows (modules/tests/stu_test.py:341-457)."""
+    """prefill + cached_forward == the delta rows of a full forward
+    (modules/tests/stu_test.py:341-457: every delta row is a target, same max_seq_len in
+    both passes so the 1/N scale agrees)."""
     from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig, STUStack
-    from generative_recommenders_amd.ops.jagged_tensors import split_2D_jagged
+    from generative_recommenders_amd.ops.jagged_tensors import asynchronous_complete_cumsum, split_2D_jagged
 
     torch.manual_seed(0)
-    D, H, A, Hd, delta = 64, 2, 32, 32, 8
-    layers = [STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=Hd, attention_dim=A,
-                                      output_dropout_ratio=0.0, target_aware=True, use_group_norm=bool(i)),
-                       is_inference=True) for i in range(2)]
-    stack = STUStack(layers, is_inference=True).to(DEV).eval()
-    B = 5
-    g = torch.Generator().manual_seed(1)
-    prime = torch.randint(5, 60, (B,), generator=g)
-    lengths = prime + delta
-    off = torch.zeros(B + 1, dtype=torch.int64)
-    off[1:] = torch.cumsum(lengths, 0)
-    N = int(lengths.max())
-    x = torch.randn(int(off[-1]), D, generator=g).to(DEV)
-    nt = torch.randint(1, delta + 1, (B,), generator=g).to(DEV)
-    offd, lend, primed = off.to(DEV), lengths.to(DEV), prime.to(DEV)
-    with torch.no_grad():
-        full = stack(x=x, x_lengths=lend, x_offsets=offd, max_seq_len=N, num_targets=nt)
-        # prefill on the prime part only, caching all of it
-        prime_off = torch.zeros(B + 1, dtype=torch.int64, device=DEV)
-        prime_off[1:] = torch.cumsum(primed, 0)
-        delta_off = delta * torch.arange(B + 1, device=DEV)
-        prime_x, delta_x = split_2D_jagged(N, x, None, None, None, delta, prime_off, None)
-        stack(x=prime_x, x_lengths=primed, x_offsets=prime_off, max_seq_len=int(prime.max()),
-              num_targets=torch.zeros_like(nt), kv_caching_lengths=primed)
-        inc = stack.cached_forward(delta_x=delta_x, num_targets=nt)
-        _, full_tail = split_2D_jagged(N, full, None, None, None, delta, prime_off, None)
-    del delta_off
-    torch.testing.assert_close(inc, full_tail, rtol=1e-4, atol=1e-5)
+    D, H, A, Hd, delta = 64, 2, 32, 32, 20
+    for ctx in (0, 4):
+        layers = [STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=Hd, attention_dim=A,
+                                          output_dropout_ratio=0.0, target_aware=True, use_group_norm=bool(i),
+                                          contextual_seq_len=ctx), is_inference=True) for i in range(2)]
+        stack = STUStack(layers, is_inference=True).to(DEV).eval()
+        B, max_uih = 5, 60
+        g = torch.Generator().manual_seed(1)
+        nt = torch.randint(delta, 2 * delta + 1, (B,), generator=g)
+        lengths = torch.randint(1, max_uih + 1, (B,), generator=g) + nt + ctx
+        N = max_uih + 2 * delta + ctx
+        x = torch.randn(int(lengths.sum()), D, generator=g).to(DEV)
+        lend, ntd = lengths.to(DEV), nt.to(DEV)
+        offd = asynchronous_complete_cumsum(lend)
+        with torch.no_grad():
+            full = stack(x=x, x_lengths=lend, x_offsets=offd, max_seq_len=N, num_targets=ntd)
+            prime_len = lend - delta
+            prime_off = asynchronous_complete_cumsum(prime_len)
+            _, full_tail = split_2D_jagged(N, full, None, None, None, delta, prime_off, None)
+            prime_x, delta_x = split_2D_jagged(N, x, None, None, None, delta, prime_off, None)
+            stack(x=prime_x, x_lengths=prime_len, x_offsets=prime_off, max_seq_len=N, num_targets=ntd - delta,
+                  max_kv_caching_len=N - delta, kv_caching_lengths=prime_len)
+            inc = stack.cached_forward(delta_x=delta_x, num_targets=ntd)
+        torch.testing.assert_close(inc, full_tail, rtol=1e-4, atol=1e-5)
 
 
 def test_silu_matches_torch():
