@@ -166,6 +166,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const float ds_scale = p.scale * p.alpha;
   const int key = k0w + n32;
   const bool key_ok = tile_owner && key < len;
+  const int key_id = mc.id_of(key);
 
   for (int it = it_lo; it < it_hi; ++it) {
     const int i0 = it << 5;
@@ -202,24 +203,32 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
       // P' = silu(x), dS' = dP silu'(x) with x = alpha S; scale and alpha are applied in fp32
       // to the accumulators at the very end (dV *= scale; dK, dQ *= scale * alpha)
       Frag pb[2], dsb[2];
-      if (mc.pair_fully_valid(i0, 32, k0w, 32)) {
+      const bool interior = mc.pair_fully_valid(i0, 32, k0w, 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float x = s[r] * p.alpha;
-          const float sg = fast_sigmoid(x);
-          E::set(pb[r >> 3], r & 7, x * sg);
-          E::set(dsb[r >> 3], r & 7, dp[r] * sg * (1.f + x * (1.f - sg)));
-        }
-      } else {
+      for (int h8 = 0; h8 < 2; ++h8) {
+        float pv[8], dsv[8];
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-          const float x = s[r] * p.alpha;
-          const float sg = fast_sigmoid(x);
-          const bool ok = key_ok && qi < len && mc.valid(qi, key);
-          E::set(pb[r >> 3], r & 7, ok ? x * sg : 0.f);
-          E::set(dsb[r >> 3], r & 7, ok ? dp[r] * sg * (1.f + x * (1.f - sg)) : 0.f);
+          for (int j = 0; j < 8; ++j) {
+            const float x = s[8 * h8 + j] * p.alpha;
+            const float sg = fast_sigmoid(x);
+            pv[j] = x * sg;
+            dsv[j] = dp[8 * h8 + j] * sg * (1.f + x * (1.f - sg));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * h8 + j;
+            const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const float x = s[r] * p.alpha;
+            const float sg = fast_sigmoid(x);
+            const bool ok = key_ok & (qi < len) & mc.valid_ids(qi, key, mc.id_of(qi), key_id);
+            pv[j] = ok ? x * sg : 0.f;
+            dsv[j] = ok ? dp[r] * sg * (1.f + x * (1.f - sg)) : 0.f;
+          }
         }
+        pb[h8] = E::pack8(pv);
+        dsb[h8] = E::pack8(dsv);
       }
       // dV_w^T[dv][key] += dO_i^T[dv][q] P[q][key]
 #pragma unroll
@@ -237,16 +246,16 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           Frag a = lds_col_frag<T, C::UPR_K>(Qs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
           dk_acc[d] = E::mma(a, dsb[ks], dk_acc[d]);
         }
-      // publish dS as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3), rq = 0..3
+      // publish dS' as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3), rq = 0..3,
+      // i.e. slots 4 (rq & 1) .. +3 of dsb[rq >> 1]
       char* myds = dsbuf + wave * C::DSBUF + n32 * C::DSROW;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int qloc = 4 * hf + 8 * rq;
         if constexpr (C::EB == 2) {
-          typedef T t4 __attribute__((ext_vector_type(4)));
-          t4 v4 = {dsb[rq >> 1].v[(rq & 1) * 4 + 0], dsb[rq >> 1].v[(rq & 1) * 4 + 1], dsb[rq >> 1].v[(rq & 1) * 4 + 2],
-                   dsb[rq >> 1].v[(rq & 1) * 4 + 3]};
-          *LDS_PTR(u32x2, myds + qloc * 2) = __builtin_bit_cast(u32x2, v4);
+          const u32x4 w = __builtin_bit_cast(u32x4, dsb[rq >> 1].v);
+          u32x2 v2 = {w[2 * (rq & 1)], w[2 * (rq & 1) + 1]};
+          *LDS_PTR(u32x2, myds + qloc * 2) = v2;
         } else {
           f32x4 v4 = {dsb[rq >> 1].v[(rq & 1) * 4 + 0], dsb[rq >> 1].v[(rq & 1) * 4 + 1], dsb[rq >> 1].v[(rq & 1) * 4 + 2],
                       dsb[rq >> 1].v[(rq & 1) * 4 + 3]};

@@ -23,6 +23,9 @@
 namespace hstu {
 
 constexpr int kFwdThreads = 256;
+#ifndef HSTU_FWD_MIN_WAVES
+#define HSTU_FWD_MIN_WAVES 2
+#endif
 constexpr int kFwdRowsPerBlock = 128;
 
 template <typename T, int DQK, int DV>
@@ -92,9 +95,8 @@ HSTU_DEV typename Elem<T>::Frag global_row_frag(const char* row_ptr, int e0, boo
 template <typename T>
 HSTU_DEV void store4(char* row_ptr, int d0, float x0, float x1, float x2, float x3) {
   if constexpr (Elem<T>::kBytes == 2) {
-    typedef T t4 __attribute__((ext_vector_type(4)));
-    t4 v = {(T)x0, (T)x1, (T)x2, (T)x3};
-    *reinterpret_cast<u32x2*>(row_ptr + d0 * 2) = __builtin_bit_cast(u32x2, v);
+    u32x2 v = {Elem<T>::pk2(x0, x1), Elem<T>::pk2(x2, x3)};
+    *reinterpret_cast<u32x2*>(row_ptr + d0 * 2) = v;
   } else {
     f32x4 v = {x0, x1, x2, x3};
     *reinterpret_cast<f32x4*>(row_ptr + d0 * 4) = v;
@@ -102,7 +104,7 @@ HSTU_DEV void store4(char* row_ptr, int d0, float x0, float x1, float x2, float 
 }
 
 template <typename T, int DQK, int DV>
-__global__ __launch_bounds__(kFwdThreads) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb) {
+__global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb) {
   using C = FwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -137,6 +139,8 @@ __global__ __launch_bounds__(kFwdThreads) void hstu_attn_fwd_kernel(const HstuAt
   const int my_row = r0 + n32;
   const bool row_ok = my_row < nq_rows;
   const int qi = my_row + i_shift;               // logical position of this lane's query
+
+  const int qi_id = mc.id_of(qi);
 
   // ---- key range visited by this workgroup (conservative; the per-element mask is exact)
   const int i_first = q0 + i_shift;
@@ -203,20 +207,27 @@ __global__ __launch_bounds__(kFwdThreads) void hstu_attn_fwd_kernel(const HstuAt
       // P' = silu(alpha S) [* mask]; the 1/N scale is applied once, in fp32, in the epilogue
       // (keeps P' in the normal range of fp16/bf16 and saves a multiply per element)
       Frag pb[2];
-      if (mc.pair_fully_valid(r0 + i_shift, 32, j0, 32)) {
+      const bool interior = mc.pair_fully_valid(r0 + i_shift, 32, j0, 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float x = s[r] * p.alpha;
-          E::set(pb[r >> 3], r & 7, x * fast_sigmoid(x));
-        }
-      } else {
+      for (int h8 = 0; h8 < 2; ++h8) {   // two halves keep only 8 fp32 temporaries live
+        float pv[8];
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-          const float x = s[r] * p.alpha;
-          const bool ok = row_ok && key < len && mc.valid(qi, key);
-          E::set(pb[r >> 3], r & 7, ok ? x * fast_sigmoid(x) : 0.f);
+          for (int j = 0; j < 8; ++j) {
+            const float x = s[8 * h8 + j] * p.alpha;
+            pv[j] = x * fast_sigmoid(x);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * h8 + j;
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const float x = s[r] * p.alpha;
+            const bool ok = row_ok & (key < len) & mc.valid_ids(qi, key, qi_id, mc.id_of(key));
+            pv[j] = ok ? x * fast_sigmoid(x) : 0.f;
+          }
         }
+        pb[h8] = E::pack8(pv);
       }
 #pragma unroll
       for (int d = 0; d < C::DB; ++d) {

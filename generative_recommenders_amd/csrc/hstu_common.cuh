@@ -47,7 +47,18 @@ template <> struct Elem<bf16_t> {
   static HSTU_DEV f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
   }
-  static HSTU_DEV void set(Frag& f, int j, float x) { f.v[j] = (bf16_t)x; }
+  static HSTU_DEV uint32_t pk2(float a, float b) {   // one v_cvt_pk_bf16_f32
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef bf16_t h2 __attribute__((ext_vector_type(2)));
+    f2 x = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, h2));
+  }
+  static HSTU_DEV Frag pack8(const float* x) {
+    u32x4 w = {pk2(x[0], x[1]), pk2(x[2], x[3]), pk2(x[4], x[5]), pk2(x[6], x[7])};
+    Frag f;
+    f.v = __builtin_bit_cast(vec8, w);
+    return f;
+  }
 };
 
 template <> struct Elem<f16_t> {
@@ -58,7 +69,18 @@ template <> struct Elem<f16_t> {
   static HSTU_DEV f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, c, 0, 0, 0);
   }
-  static HSTU_DEV void set(Frag& f, int j, float x) { f.v[j] = (f16_t)x; }
+  static HSTU_DEV uint32_t pk2(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef f16_t h2 __attribute__((ext_vector_type(2)));
+    f2 x = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, h2));
+  }
+  static HSTU_DEV Frag pack8(const float* x) {
+    u32x4 w = {pk2(x[0], x[1]), pk2(x[2], x[3]), pk2(x[4], x[5]), pk2(x[6], x[7])};
+    Frag f;
+    f.v = __builtin_bit_cast(vec8, w);
+    return f;
+  }
 };
 
 template <> struct Elem<float> {
@@ -72,7 +94,12 @@ template <> struct Elem<float> {
     for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], c, 0, 0, 0);
     return c;
   }
-  static HSTU_DEV void set(Frag& f, int j, float x) { f.v[j] = x; }
+  static HSTU_DEV Frag pack8(const float* x) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = x[j];
+    return f;
+  }
 };
 
 template <typename T> HSTU_DEV float to_f32(T x) { return (float)x; }
@@ -163,8 +190,8 @@ struct MaskCtx {
     return has_targets ? min(id, max_id) : id;
   }
   // row position i (query), col position j (key); both < len
-  HSTU_DEV bool valid(int i, int j) const {
-    const int idi = id_of(i), idj = id_of(j);
+  HSTU_DEV bool valid(int i, int j) const { return valid_ids(i, j, id_of(i), id_of(j)); }
+  HSTU_DEV bool valid_ids(int i, int j, int idi, int idj) const {
     const int d = idi - idj;
     bool m = (i == j) | (d > 0);
     if (win > 0) m = m & ((d <= win) | ((full > 0) & (idi >= max_id - full)));

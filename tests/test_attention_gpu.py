@@ -11,6 +11,10 @@ Tolerances (stated once, used everywhere):
              RMS, and P is rounded to bf16 before the second MFMA exactly as the reference's
              Triton kernel does, so 1e-3 is not reachable with bf16 outputs by any kernel;
              the reference's own bf16 test tolerance is rtol=1.6e-2.)
+  fp16     : additionally one fp16 subnormal quantum (2^-24) of absolute slack per element: with
+             the reference test's input distribution (uniform +-0.1, small head dims, /N) the true
+             outputs are ~1e-5, i.e. BELOW fp16's smallest normal 6.1e-5, so any fp16 output
+             carries that absolute rounding error.
 """
 
 import os
@@ -43,9 +47,11 @@ def check_close(got: torch.Tensor, ref: np.ndarray, dtype, what=""):
     if dtype == torch.float32:
         bad = err > 1e-3 * np.abs(ref) + 1e-6 * scale
     else:
-        fro = np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-30)
+        quantum = 2.0**-24 if dtype == torch.float16 else 0.0
+        resid = np.maximum(err - quantum, 0.0)
+        fro = np.linalg.norm(resid) / max(np.linalg.norm(ref), 1e-30)
         assert fro <= 4e-3, f"{what}: relative Frobenius error {fro:.3e}"
-        bad = err > 2e-2 * np.abs(ref) + 4e-3 * scale
+        bad = err > 2e-2 * np.abs(ref) + 4e-3 * scale + quantum
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements out of tolerance, max err {err.max():.3e} (scale {scale:.3e})"
 
 
