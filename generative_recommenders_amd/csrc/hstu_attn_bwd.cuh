@@ -51,10 +51,12 @@ struct BwdCfg {
   static constexpr int DBV = DV / 32;
   static constexpr int NQU = (32 * UPR_K + kBwdThreads - 1) / kBwdThreads;
   static constexpr int NOU = (32 * UPR_V + kBwdThreads - 1) / kBwdThreads;
-  static constexpr int smem_bytes(int nw) { return nw * PAIR + PAIR + nw * DSBUF; }
+  static constexpr int smem_bytes(int nw) { return nw * PAIR + PAIR + 2 * nw * DSBUF; }
+  // at most 7 key tiles per block: the 8th wave never owns a tile, so every step has a
+  // helper wave for the dQ GEMM of the previous step
   static constexpr int max_tiles(int lds_budget) {
-    int nw = (lds_budget - PAIR) / (PAIR + DSBUF);
-    return nw > kBwdWaves ? kBwdWaves : nw;
+    int nw = (lds_budget - PAIR) / (PAIR + 2 * DSBUF);
+    return nw > kBwdWaves - 1 ? kBwdWaves - 1 : nw;
   }
 };
 
@@ -80,6 +82,92 @@ HSTU_DEV typename Elem<T>::Frag dsbuf_col_frag(const char* buf, int rowA, int ro
     }
   }
   return f;
+}
+
+// dQ_i^T blocks [32 db, +32) for db = db0, db0 + dstep, ... (NB at a time) of query tile i0:
+// sum over the block's key tiles of K_w^T dS'_w^T, then scale and store (or atomically add to
+// the fp32 workspace).  Executed by ONE wave; the dS' fragments are read once per key tile and
+// shared by the NB output blocks, and NB independent MFMA chains hide each other's latency.
+template <typename T, int DQK, int DV, int NB>
+HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* smem, const char* ds_base,
+                            int nw, int kb0, int i0, int db0, int dstep, int64_t off0, int hd, float ds_scale,
+                            float* dq_accum, int lane) {
+  using C = BwdCfg<T, DQK, DV>;
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  const HstuAttnParams& p = bp.fwd;
+  const int n32 = lane & 31, hf = lane >> 5;
+  const int len = mc.len;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  for (int w2 = 0; w2 < nw; ++w2) {
+    const int k0 = kb0 + 32 * w2;
+    if (k0 >= len || !mc.pair_may_be_active(i0, 32, k0, 32)) continue;   // wave-uniform
+    const char* Kt = smem + w2 * C::PAIR;
+    const char* ds = ds_base + w2 * C::DSBUF;
+    const int ra = 8 * hf, rb = 16 + 8 * hf;
+    Frag b0 = dsbuf_col_frag<T, C::DSROW>(ds, ra, ra + 4, lane);             // dS'^T[key][q]
+    Frag b1 = dsbuf_col_frag<T, C::DSROW>(ds, rb, rb + 4, lane);
+    Frag a0[NB], a1[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int db = db0 + n * dstep;
+      a0[n] = lds_col_frag<T, C::UPR_K>(Kt, ra, ra + 4, 32 * db, lane);      // K^T[d][key]
+      a1[n] = lds_col_frag<T, C::UPR_K>(Kt, rb, rb + 4, 32 * db, lane);
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[n] = E::mma(a0[n], b0, acc[n]);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[n] = E::mma(a1[n], b1, acc[n]);
+  }
+  // C layout: column n32 = query row, register r = d within the 32-block
+  const int qrow = i0 + n32;
+  if (qrow < len) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int db = db0 + n * dstep;
+      if (dq_accum == nullptr) {
+        char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d0 = 32 * db + 8 * rq + 4 * hf;
+          if (d0 < p.dqk)
+            store4<T>(dqrow, d0, acc[n][4 * rq] * ds_scale, acc[n][4 * rq + 1] * ds_scale, acc[n][4 * rq + 2] * ds_scale,
+                      acc[n][4 * rq + 3] * ds_scale);
+        }
+      } else {
+        float* arow = dq_accum + ((off0 + qrow) * p.heads + hd) * (int64_t)p.dqk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = 32 * db + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          if (d < p.dqk) atomicAdd(arow + d, acc[n][r] * ds_scale);
+        }
+      }
+    }
+  }
+}
+
+// all DBQ output blocks of one query tile, dealt to `n_help` waves; this wave has rank `rank`
+template <typename T, int DQK, int DV>
+HSTU_DEV void bwd_dq_tile(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* smem, const char* ds_base, int nw,
+                          int kb0, int i0, int rank, int n_help, int64_t off0, int hd, float ds_scale, float* dq_accum,
+                          int lane) {
+  constexpr int DBQ = DQK / 32;
+  if constexpr (DBQ >= 2) {
+    if (2 * n_help <= DBQ) {   // few helpers: each takes pairs of blocks (rank, rank + n_help), ...
+      for (int db = rank; db + n_help < DBQ; db += 2 * n_help)
+        bwd_dq_blocks<T, DQK, DV, 2>(bp, mc, smem, ds_base, nw, kb0, i0, db, n_help, off0, hd, ds_scale, dq_accum, lane);
+      if ((DBQ / n_help) & 1)  // odd number of rounds: one single block left per helper
+        for (int db = rank + (DBQ / n_help - 1) * n_help; db < DBQ; db += n_help)
+          bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, lane);
+      return;
+    }
+  }
+  for (int db = rank; db < DBQ; db += n_help)
+    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, lane);
 }
 
 template <typename T, int DQK, int DV>
@@ -108,9 +196,11 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int kb0 = kb * 32 * nw;
   if (kb0 >= len) return;
   const MaskCtx mc = make_mask_ctx(p, b, len);
+  HSTU_TRACE_DECL(bp.workspace, bp.workspace != nullptr && dq_accum == nullptr && blockIdx.x == 4096);
+  HSTU_MARK(1);
 
   char* const stage = smem + nw * C::PAIR;           // Q_i tile then dO_i tile
-  char* const dsbuf = stage + C::PAIR;               // nw buffers of [32 keys][32 q]
+  char* const dsbuf = stage + C::PAIR;               // 2 x nw buffers of [32 keys][32 q] (double buffered)
   const int k0w = kb0 + 32 * wave;                   // first key of this wave's tile
   const bool tile_owner = wave < nw && k0w < len;
 
@@ -121,30 +211,37 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int64_t q_rs = p.q_row_stride * C::EB, k_rs = p.k_row_stride * C::EB, v_rs = p.v_row_stride * C::EB,
                 do_rs = bp.do_row_stride * C::EB;
 
-  // ---- resident K/V block -> LDS (zero-filled past len / past the real head dims)
-  {
-    const int nrows = 32 * nw;
-    for (int u = tid; u < nrows * C::UPR_K; u += kBwdThreads) {
-      const int row = u / C::UPR_K, unit = u % C::UPR_K;
-      const bool ok = (kb0 + row < len) && (unit * C::EPU < p.dqk);
-      u32x4 z = {0u, 0u, 0u, 0u};
-      u32x4 x = ok ? gload16(kbase + (int64_t)(kb0 + row) * k_rs + unit * 16) : z;
-      *LDS_PTR(u32x4, smem + (row >> 5) * C::PAIR + tile_off<C::UPR_K>(row & 31, unit)) = x;
-    }
-    for (int u = tid; u < nrows * C::UPR_V; u += kBwdThreads) {
-      const int row = u / C::UPR_V, unit = u % C::UPR_V;
-      const bool ok = (kb0 + row < len) && (unit * C::EPU < p.dv);
-      u32x4 z = {0u, 0u, 0u, 0u};
-      u32x4 x = ok ? gload16(vbase + (int64_t)(kb0 + row) * v_rs + unit * 16) : z;
-      *LDS_PTR(u32x4, smem + (row >> 5) * C::PAIR + C::KT + tile_off<C::UPR_V>(row & 31, unit)) = x;
-    }
-  }
-
-  // ---- query-tile range: rows at or below the block's first key; contextual rows (id 0)
-  // see every key, so start from 0 when they exist (inactive pairs are skipped per wave)
-  const int it_lo = (mc.ctx > 0) ? 0 : (kb0 >> 5);
+  // ---- query tiles are visited in DESCENDING order.  Tile i needs key tiles <= i (causal), so
+  // the steps with many active owner waves come first and every later step frees one more
+  // wave: those idle waves run the dQ GEMM of the PREVIOUS step (whose cost shrinks at the same
+  // pace), and an owner that has seen its last query tile stores dK/dV while the others go on.
+  const int kt0 = kb0 >> 5;
+  const int it_lo = (mc.ctx > 0) ? 0 : kt0;          // contextual rows (id 0) see every key
   const int it_hi = (len + 31) >> 5;
-  const int kb_hi = min(kb0 + 32 * nw, len);        // one past the last key of this block
+
+  // ---- resident K/V block: all loads in flight at once (registers are free before the
+  // accumulators become live), then written to LDS
+  for (int wb = 0; wb < nw; wb += 4) {   // 4 tiles (8 loads of 16 B per thread) in flight per round
+    u32x4 kr[4][C::NQU], vr[4][C::NOU];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (wb + j < nw && kb0 + 32 * (wb + j) < len) {
+        tile_gload<T, DQK, C::NQU, kBwdThreads>(kr[j], kbase, k_rs, kb0 + 32 * (wb + j), len, p.dqk, tid);
+        tile_gload<T, DV, C::NOU, kBwdThreads>(vr[j], vbase, v_rs, kb0 + 32 * (wb + j), len, p.dv, tid);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (wb + j < nw && kb0 + 32 * (wb + j) < len) {
+        tile_lds_write<T, DQK, C::NQU, kBwdThreads>(kr[j], smem + (wb + j) * C::PAIR, kb0 + 32 * (wb + j), len, p.dqk, tid);
+        tile_lds_write<T, DV, C::NOU, kBwdThreads>(vr[j], smem + (wb + j) * C::PAIR + C::KT, kb0 + 32 * (wb + j), len, p.dv, tid);
+      }
+  }
+  HSTU_MARK(2);
+  u32x4 qreg[C::NQU], oreg[C::NOU];
+  tile_gload<T, DQK, C::NQU, kBwdThreads>(qreg, qbase, q_rs, (it_hi - 1) * 32, len, p.dqk, tid);
+  tile_gload<T, DV, C::NOU, kBwdThreads>(oreg, dobase, do_rs, (it_hi - 1) * 32, len, p.dv, tid);
+  tile_lds_write<T, DQK, C::NQU, kBwdThreads>(qreg, stage, (it_hi - 1) * 32, len, p.dqk, tid);
+  tile_lds_write<T, DV, C::NOU, kBwdThreads>(oreg, stage + C::KT, (it_hi - 1) * 32, len, p.dv, tid);
 
   f32x16 dk_acc[C::DBQ], dv_acc[C::DBV];
 #pragma unroll
@@ -155,29 +252,27 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   for (int d = 0; d < C::DBV; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv_acc[d][r] = 0.f;
-
-  u32x4 qreg[C::NQU], oreg[C::NOU];
-  tile_gload<T, DQK, C::NQU, kBwdThreads>(qreg, qbase, q_rs, it_lo * 32, len, p.dqk, tid);
-  tile_gload<T, DV, C::NOU, kBwdThreads>(oreg, dobase, do_rs, it_lo * 32, len, p.dv, tid);
-  tile_lds_write<T, DQK, C::NQU, kBwdThreads>(qreg, stage, tid);
-  tile_lds_write<T, DV, C::NOU, kBwdThreads>(oreg, stage + C::KT, tid);
   __syncthreads();
+  HSTU_MARK(3);
 
   const float ds_scale = p.scale * p.alpha;
   const int key = k0w + n32;
   const bool key_ok = tile_owner && key < len;
   const int key_id = mc.id_of(key);
+  // last (smallest) query tile this owner takes part in: its diagonal, or tile 0 with contextual rows
+  const int my_last_it = (mc.ctx > 0) ? it_lo : max(it_lo, kt0 + wave);
 
-  for (int it = it_lo; it < it_hi; ++it) {
+  for (int it = it_hi - 1; it >= it_lo; --it) {
     const int i0 = it << 5;
-    const bool more = it + 1 < it_hi;
+    const bool more = it > it_lo;
     if (more) {
-      tile_gload<T, DQK, C::NQU, kBwdThreads>(qreg, qbase, q_rs, i0 + 32, len, p.dqk, tid);
-      tile_gload<T, DV, C::NOU, kBwdThreads>(oreg, dobase, do_rs, i0 + 32, len, p.dv, tid);
+      tile_gload<T, DQK, C::NQU, kBwdThreads>(qreg, qbase, q_rs, i0 - 32, len, p.dqk, tid);
+      tile_gload<T, DV, C::NOU, kBwdThreads>(oreg, dobase, do_rs, i0 - 32, len, p.dv, tid);
     }
-
-    // ------------------------------ phase 1 ------------------------------
-    if (tile_owner && mc.pair_may_be_active(i0, 32, k0w, 32)) {
+    HSTU_MARK(10);
+    const bool active = tile_owner && mc.pair_may_be_active(i0, 32, k0w, 32);
+    if (active) {
+      // ------------------------------ phase 1 (owner of key tile `wave`) ------------------------------
       const char* Kw = smem + wave * C::PAIR;
       const char* Vw = Kw + C::KT;
       const char* Qs = stage;
@@ -199,38 +294,47 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         Frag bb = lds_row_frag<T, C::UPR_V>(Vw, n32, e0);
         dp = E::mma(a, bb, dp);
       }
-      // C layout: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf
+      HSTU_MARK(11);
+      // C layout: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf.
       // P' = silu(x), dS' = dP silu'(x) with x = alpha S; scale and alpha are applied in fp32
       // to the accumulators at the very end (dV *= scale; dK, dQ *= scale * alpha)
       Frag pb[2], dsb[2];
-      const bool interior = mc.pair_fully_valid(i0, 32, k0w, 32);
+      const int mode = mc.pair_fully_valid(i0, 32, k0w, 32) ? 0 : (mc.simple ? 1 : 2);   // wave-uniform
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {
         float pv[8], dsv[8];
-        if (interior) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float x = s[8 * h8 + j] * p.alpha;
-            const float sg = fast_sigmoid(x);
-            pv[j] = x * sg;
-            dsv[j] = dp[8 * h8 + j] * sg * (1.f + x * (1.f - sg));
-          }
-        } else {
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * h8 + j;
+          const float x = s[r] * p.alpha;
+          const float sg = fast_sigmoid(x);
+          pv[j] = x * sg;
+          dsv[j] = dp[r] * sg * (1.f + x * (1.f - sg));
+        }
+        if (mode == 1) {          // plain causal, no targets: key <= query (and both in range)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int r = 8 * h8 + j;
             const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const float x = s[r] * p.alpha;
-            const float sg = fast_sigmoid(x);
+            const bool ok = key_ok & (qi < len) & (key <= qi);
+            pv[j] = ok ? pv[j] : 0.f;
+            dsv[j] = ok ? dsv[j] : 0.f;
+          }
+        } else if (mode == 2) {   // general mask algebra
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * h8 + j;
+            const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             const bool ok = key_ok & (qi < len) & mc.valid_ids(qi, key, mc.id_of(qi), key_id);
-            pv[j] = ok ? x * sg : 0.f;
-            dsv[j] = ok ? dp[r] * sg * (1.f + x * (1.f - sg)) : 0.f;
+            pv[j] = ok ? pv[j] : 0.f;
+            dsv[j] = ok ? dsv[j] : 0.f;
           }
         }
         pb[h8] = E::pack8(pv);
         dsb[h8] = E::pack8(dsv);
       }
-      // dV_w^T[dv][key] += dO_i^T[dv][q] P[q][key]
+      HSTU_MARK(12);
+      // dV_w^T[dv][key] += dO_i^T[dv][q] P'[q][key]
 #pragma unroll
       for (int d = 0; d < C::DBV; ++d)
 #pragma unroll
@@ -238,7 +342,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           Frag a = lds_col_frag<T, C::UPR_V>(dOs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
           dv_acc[d] = E::mma(a, pb[ks], dv_acc[d]);
         }
-      // dK_w^T[d][key] += Q_i^T[d][q] dS[q][key]
+      // dK_w^T[d][key] += Q_i^T[d][q] dS'[q][key]
 #pragma unroll
       for (int d = 0; d < C::DBQ; ++d)
 #pragma unroll
@@ -246,9 +350,10 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           Frag a = lds_col_frag<T, C::UPR_K>(Qs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
           dk_acc[d] = E::mma(a, dsb[ks], dk_acc[d]);
         }
+      HSTU_MARK(13);
       // publish dS' as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3), rq = 0..3,
       // i.e. slots 4 (rq & 1) .. +3 of dsb[rq >> 1]
-      char* myds = dsbuf + wave * C::DSBUF + n32 * C::DSROW;
+      char* myds = dsbuf + ((it & 1) * nw + wave) * C::DSBUF + n32 * C::DSROW;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int qloc = 4 * hf + 8 * rq;
@@ -262,81 +367,62 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           *LDS_PTR(f32x4, myds + qloc * 4) = v4;
         }
       }
+    } else if (it + 1 < it_hi) {
+      // ------------------------------ dQ GEMM of the PREVIOUS step (query tile it+1), on an idle wave ------------------------------
+      // helpers = waves without phase-1 work in this step (wave 7 never owns a tile, so there is
+      // always one); the DQK/32 output blocks are dealt round-robin to them.
+      int n_help = 0, my_rank = 0;
+      for (int w2 = 0; w2 < kBwdWaves; ++w2) {
+        const bool act = w2 < nw && (kb0 + 32 * w2) < len && mc.pair_may_be_active(i0, 32, kb0 + 32 * w2, 32);
+        if (!act) {
+          if (w2 < wave) ++my_rank;
+          ++n_help;
+        }
+      }
+      const char* ds_prev = dsbuf + (((it + 1) & 1) * nw) * C::DSBUF;
+      bwd_dq_tile<T, DQK, DV>(bp, mc, smem, ds_prev, nw, kb0, i0 + 32, my_rank, n_help, off0, hd, ds_scale, dq_accum, lane);
     }
-    __syncthreads();  // dS of every owner visible; everybody is done reading the stage
-
+    HSTU_MARK(14);
+    __syncthreads();  // stage reads done; dS'(it) complete; dS'(it+1) consumed
+    HSTU_MARK(15);
     if (more) {
-      tile_lds_write<T, DQK, C::NQU, kBwdThreads>(qreg, stage, tid);
-      tile_lds_write<T, DV, C::NOU, kBwdThreads>(oreg, stage + C::KT, tid);
+      tile_lds_write<T, DQK, C::NQU, kBwdThreads>(qreg, stage, i0 - 32, len, p.dqk, tid);
+      tile_lds_write<T, DV, C::NOU, kBwdThreads>(oreg, stage + C::KT, i0 - 32, len, p.dv, tid);
     }
-
-    // ------------------------------ phase 2 ------------------------------
-    if (wave < C::DBQ) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int w2 = 0; w2 < nw; ++w2) {
-        const int k0 = kb0 + 32 * w2;
-        if (k0 >= len || !mc.pair_may_be_active(i0, 32, k0, 32)) continue;   // uniform
-        const char* Kt = smem + w2 * C::PAIR;
-        const char* ds = dsbuf + w2 * C::DSBUF;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int ra = 16 * ks + 8 * hf;
-          Frag a = lds_col_frag<T, C::UPR_K>(Kt, ra, ra + 4, 32 * wave, lane);      // K^T[d][key]
-          Frag bb = dsbuf_col_frag<T, C::DSROW>(ds, ra, ra + 4, lane);             // dS^T[key][q]
-          acc = E::mma(a, bb, acc);
-        }
-      }
-      // C layout: column n32 = query row, register r = d within the 32-block
-      const int qrow = i0 + n32;
-      if (qrow < len) {
-        if (dq_accum == nullptr) {
-          char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const int d0 = 32 * wave + 8 * rq + 4 * hf;
-            if (d0 < p.dqk)
-              store4<T>(dqrow, d0, acc[4 * rq] * ds_scale, acc[4 * rq + 1] * ds_scale, acc[4 * rq + 2] * ds_scale,
-                        acc[4 * rq + 3] * ds_scale);
-          }
-        } else {
-          float* arow = dq_accum + ((off0 + qrow) * p.heads + hd) * (int64_t)p.dqk;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int d = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (d < p.dqk) atomicAdd(arow + d, acc[r] * ds_scale);
-          }
-        }
-      }
-    }
-    __syncthreads();  // next stage visible; dS buffers free again
+    HSTU_MARK(16);
+    __syncthreads();  // next Q/dO tile visible
+    HSTU_MARK(18);
   }
-  (void)kb_hi;
-
+  HSTU_MARK(20);
+  // ---- dQ of the last visited query tile: every wave is idle now
+  if (it_hi > it_lo && wave < C::DBQ) {
+    const char* ds_prev = dsbuf + ((it_lo & 1) * nw) * C::DSBUF;
+    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_prev, nw, kb0, it_lo << 5, wave, 1, off0, hd, ds_scale, dq_accum, lane);
+  }
+  HSTU_MARK(21);
   // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv
   if (key_ok) {
-    char* dkrow = (char*)bp.dk + ((off0 + key) * bp.dk_row_stride + (int64_t)hd * bp.dk_head_stride) * C::EB;
-    char* dvrow = (char*)bp.dv + ((off0 + key) * bp.dv_row_stride + (int64_t)hd * bp.dv_head_stride) * C::EB;
+      char* dkrow = (char*)bp.dk + ((off0 + key) * bp.dk_row_stride + (int64_t)hd * bp.dk_head_stride) * C::EB;
+      char* dvrow = (char*)bp.dv + ((off0 + key) * bp.dv_row_stride + (int64_t)hd * bp.dv_head_stride) * C::EB;
 #pragma unroll
-    for (int d = 0; d < C::DBQ; ++d)
+      for (int d = 0; d < C::DBQ; ++d)
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d0 = 32 * d + 8 * rq + 4 * hf;
-        if (d0 < p.dqk)
-          store4<T>(dkrow, d0, dk_acc[d][4 * rq] * ds_scale, dk_acc[d][4 * rq + 1] * ds_scale, dk_acc[d][4 * rq + 2] * ds_scale,
-                    dk_acc[d][4 * rq + 3] * ds_scale);
-      }
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d0 = 32 * d + 8 * rq + 4 * hf;
+          if (d0 < p.dqk)
+            store4<T>(dkrow, d0, dk_acc[d][4 * rq] * ds_scale, dk_acc[d][4 * rq + 1] * ds_scale,
+                      dk_acc[d][4 * rq + 2] * ds_scale, dk_acc[d][4 * rq + 3] * ds_scale);
+        }
 #pragma unroll
-    for (int d = 0; d < C::DBV; ++d)
+      for (int d = 0; d < C::DBV; ++d)
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d0 = 32 * d + 8 * rq + 4 * hf;
-        if (d0 < p.dv)
-          store4<T>(dvrow, d0, dv_acc[d][4 * rq] * p.scale, dv_acc[d][4 * rq + 1] * p.scale, dv_acc[d][4 * rq + 2] * p.scale,
-                    dv_acc[d][4 * rq + 3] * p.scale);
-      }
-  }
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d0 = 32 * d + 8 * rq + 4 * hf;
+          if (d0 < p.dv)
+            store4<T>(dvrow, d0, dv_acc[d][4 * rq] * p.scale, dv_acc[d][4 * rq + 1] * p.scale, dv_acc[d][4 * rq + 2] * p.scale,
+                      dv_acc[d][4 * rq + 3] * p.scale);
+        }
+    }
 }
 
 // fp32 dq accumulator (rows, H, dqk) -> dq in the I/O dtype (strided)

@@ -44,8 +44,11 @@ struct FwdCfg {
   static constexpr int SMEM = 2 * STAGE;
 };
 
-// Cooperative global -> register load of one [32][D] tile (rows row0.., zero-filled
-// past `len` and past the real head dim), and the matching register -> LDS write.
+// Cooperative global -> register load of one [32][D] tile and the matching register -> LDS
+// write.  The loads are UNCONDITIONAL on clamped (always valid) addresses so that nothing
+// consumes the loaded registers until tile_lds_write: the global loads stay in flight across
+// the whole compute phase (a predicated `ok ? load : 0` forces an s_waitcnt right at the load).
+// Zero-fill (rows >= len, columns >= the real head dim) is applied at write time.
 template <typename T, int D, int NU, int NTHREADS>
 HSTU_DEV void tile_gload(u32x4 (&reg)[NU], const char* base, int64_t row_stride_bytes, int row0, int len,
                          int real_d, int tid) {
@@ -53,37 +56,54 @@ HSTU_DEV void tile_gload(u32x4 (&reg)[NU], const char* base, int64_t row_stride_
   constexpr int EPU = 16 / Elem<T>::kBytes;
 #pragma unroll
   for (int t = 0; t < NU; ++t) {
-    const int u = tid + t * NTHREADS;
-    const int row = u / UPR, unit = u % UPR;
-    const bool ok = (u < 32 * UPR) && (row0 + row < len) && (unit * EPU < real_d);
-    u32x4 z = {0u, 0u, 0u, 0u};
-    reg[t] = ok ? gload16(base + (int64_t)(row0 + row) * row_stride_bytes + unit * 16) : z;
+    const int u = min(tid + t * NTHREADS, 32 * UPR - 1);
+    const int row = min(row0 + u / UPR, len - 1);
+    const int unit = ((u % UPR) * EPU < real_d) ? (u % UPR) : 0;
+    reg[t] = gload16(base + (int64_t)row * row_stride_bytes + unit * 16);
   }
 }
 
 template <typename T, int D, int NU, int NTHREADS>
-HSTU_DEV void tile_lds_write(const u32x4 (&reg)[NU], char* tile, int tid) {
+HSTU_DEV void tile_lds_write(const u32x4 (&reg)[NU], char* tile, int row0, int len, int real_d, int tid) {
   constexpr int UPR = D * Elem<T>::kBytes / 16;
+  constexpr int EPU = 16 / Elem<T>::kBytes;
 #pragma unroll
   for (int t = 0; t < NU; ++t) {
     const int u = tid + t * NTHREADS;
-    if (u < 32 * UPR) *LDS_PTR(u32x4, tile + tile_off<UPR>(u / UPR, u % UPR)) = reg[t];
+    if (u < 32 * UPR) {
+      const int row = u / UPR, unit = u % UPR;
+      const bool ok = (row0 + row < len) & (unit * EPU < real_d);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *LDS_PTR(u32x4, tile + tile_off<UPR>(row, unit)) = ok ? reg[t] : z;
+    }
   }
 }
 
-// Row fragment straight from global memory: elements [e0, e0+8) of one row, zero if
-// !ok.  Used for operands a wave keeps in registers for its whole lifetime (Q here).
+// Row fragment straight from global memory (unconditional, caller clamps the address):
+// raw 16-byte pieces first, converted / zeroed by finish_row_frag once all are in flight.
+template <typename T> struct RawFrag { u32x4 x0, x1; };
+
 template <typename T>
-HSTU_DEV typename Elem<T>::Frag global_row_frag(const char* row_ptr, int e0, bool ok) {
-  typename Elem<T>::Frag f;
-  u32x4 z = {0u, 0u, 0u, 0u};
+HSTU_DEV RawFrag<T> global_row_frag_issue(const char* row_ptr, int e0) {
+  RawFrag<T> r;
   if constexpr (Elem<T>::kBytes == 2) {
-    u32x4 x = ok ? gload16(row_ptr + e0 * 2) : z;
-    f.v = __builtin_bit_cast(typename Elem<T>::vec8, x);
+    r.x0 = gload16(row_ptr + e0 * 2);
+    r.x1 = r.x0;
   } else {
-    u32x4 x0 = ok ? gload16(row_ptr + e0 * 4) : z;
-    u32x4 x1 = ok ? gload16(row_ptr + e0 * 4 + 16) : z;
-    f32x4 a = __builtin_bit_cast(f32x4, x0), b = __builtin_bit_cast(f32x4, x1);
+    r.x0 = gload16(row_ptr + e0 * 4);
+    r.x1 = gload16(row_ptr + e0 * 4 + 16);
+  }
+  return r;
+}
+
+template <typename T>
+HSTU_DEV typename Elem<T>::Frag finish_row_frag(const RawFrag<T>& r, bool ok) {
+  typename Elem<T>::Frag f;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  if constexpr (Elem<T>::kBytes == 2) {
+    f.v = __builtin_bit_cast(typename Elem<T>::vec8, ok ? r.x0 : z);
+  } else {
+    f32x4 a = __builtin_bit_cast(f32x4, ok ? r.x0 : z), b = __builtin_bit_cast(f32x4, ok ? r.x1 : z);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
   }
@@ -134,6 +154,10 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   if (q0 >= nq_rows) return;
 
   const MaskCtx mc = make_mask_ctx(p, b, len);
+#ifdef HSTU_TRACE
+  HSTU_TRACE_DECL(g_hstu_trace_fwd, g_hstu_trace_fwd != nullptr && blockIdx.x == 4096);
+#endif
+  HSTU_MARK(1);
   const int r0 = q0 + 32 * wave;                 // first q row of this wave
   const bool wave_active = r0 < nq_rows;
   const int my_row = r0 + n32;
@@ -159,14 +183,22 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   // elements hf*DQK/2 + 8*kg .. +8 of its row: one contiguous half row per lane.
   Frag qf[C::KG];
   {
-    const char* qrow = (const char*)p.q + ((q_base + my_row) * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
+    const int ld_row = min(my_row, nq_rows - 1);   // clamped: always a valid row of this user
+    const char* qrow = (const char*)p.q + ((q_base + ld_row) * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
+    RawFrag<T> raw[C::KG];
 #pragma unroll
     for (int kg = 0; kg < C::KG; ++kg) {
       const int e0 = hf * (DQK / 2) + kg * 8;
-      qf[kg] = global_row_frag<T>(qrow, e0, row_ok && e0 < p.dqk);
+      raw[kg] = global_row_frag_issue<T>(qrow, e0 < p.dqk ? e0 : 0);
+    }
+#pragma unroll
+    for (int kg = 0; kg < C::KG; ++kg) {
+      const int e0 = hf * (DQK / 2) + kg * 8;
+      qf[kg] = finish_row_frag<T>(raw[kg], row_ok && e0 < p.dqk);
     }
   }
 
+  HSTU_MARK(2);
   const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
   const char* vbase = (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * C::EB;
   const int64_t k_rs = p.k_row_stride * C::EB, v_rs = p.v_row_stride * C::EB;
@@ -181,10 +213,11 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   if (ntiles > 0) {
     tile_gload<T, DQK, C::NKU, kFwdThreads>(kreg, kbase, k_rs, kv_lo, len, p.dqk, tid);
     tile_gload<T, DV, C::NVU, kFwdThreads>(vreg, vbase, v_rs, kv_lo, len, p.dv, tid);
-    tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, smem, tid);
-    tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, smem + C::KT, tid);
+    tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, smem, kv_lo, len, p.dqk, tid);
+    tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, smem + C::KT, kv_lo, len, p.dv, tid);
   }
   __syncthreads();
+  HSTU_MARK(3);
 
   for (int t = 0; t < ntiles; ++t) {
     const int j0 = kv_lo + (t << 5);
@@ -193,42 +226,53 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       tile_gload<T, DQK, C::NKU, kFwdThreads>(kreg, kbase, k_rs, j0 + 32, len, p.dqk, tid);
       tile_gload<T, DV, C::NVU, kFwdThreads>(vreg, vbase, v_rs, j0 + 32, len, p.dv, tid);
     }
+    HSTU_MARK(10);
     if (wave_active && mc.pair_may_be_active(r0 + i_shift, 32, j0, 32)) {
       const char* Kt = smem + (t & 1) * C::STAGE;
       const char* Vt = Kt + C::KT;
-      f32x16 s;
+      f32x16 s, s1;   // two accumulators halve the dependent-MFMA chain of the QK^T contraction
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
       for (int kg = 0; kg < C::KG; ++kg) {
         Frag a = lds_row_frag<T, C::UPR_K>(Kt, n32, hf * (DQK / 2) + kg * 8);
-        s = E::mma(a, qf[kg], s);
+        if (kg & 1) s1 = E::mma(a, qf[kg], s1);
+        else s = E::mma(a, qf[kg], s);
       }
-      // P' = silu(alpha S) [* mask]; the 1/N scale is applied once, in fp32, in the epilogue
-      // (keeps P' in the normal range of fp16/bf16 and saves a multiply per element)
+      if constexpr (C::KG > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += s1[r];
+      }
+      HSTU_MARK(11);
       Frag pb[2];
-      const bool interior = mc.pair_fully_valid(r0 + i_shift, 32, j0, 32);
+      const int mode = mc.pair_fully_valid(r0 + i_shift, 32, j0, 32) ? 0 : (mc.simple ? 1 : 2);   // wave-uniform
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {   // two halves keep only 8 fp32 temporaries live
         float pv[8];
-        if (interior) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float x = s[8 * h8 + j] * p.alpha;
-            pv[j] = x * fast_sigmoid(x);
-          }
-        } else {
+        for (int j = 0; j < 8; ++j) {
+          const float x = s[8 * h8 + j] * p.alpha;
+          pv[j] = x * fast_sigmoid(x);
+        }
+        if (mode == 1) {          // plain causal: key <= query, both in range
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int r = 8 * h8 + j;
             const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const float x = s[r] * p.alpha;
+            pv[j] = (row_ok & (key < len) & (key <= qi)) ? pv[j] : 0.f;
+          }
+        } else if (mode == 2) {   // general mask algebra
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * h8 + j;
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             const bool ok = row_ok & (key < len) & mc.valid_ids(qi, key, qi_id, mc.id_of(key));
-            pv[j] = ok ? x * fast_sigmoid(x) : 0.f;
+            pv[j] = ok ? pv[j] : 0.f;
           }
         }
         pb[h8] = E::pack8(pv);
       }
+      HSTU_MARK(12);
 #pragma unroll
       for (int d = 0; d < C::DB; ++d) {
 #pragma unroll
@@ -238,13 +282,17 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         }
       }
     }
+    HSTU_MARK(13);
     if (more) {
       char* nxt = smem + ((t + 1) & 1) * C::STAGE;
-      tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, nxt, tid);
-      tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, nxt + C::KT, tid);
+      tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, nxt, j0 + 32, len, p.dqk, tid);
+      tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, nxt + C::KT, j0 + 32, len, p.dv, tid);
     }
+    HSTU_MARK(14);
     __syncthreads();
+    HSTU_MARK(15);
   }
+  HSTU_MARK(20);
 
   // ---- epilogue: O^T accumulators -> out rows
   if (row_ok) {
@@ -260,6 +308,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       }
     }
   }
+  HSTU_MARK(21);
 }
 
 }  // namespace hstu

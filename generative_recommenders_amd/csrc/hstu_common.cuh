@@ -184,6 +184,7 @@ struct MaskCtx {
   int win;        // max_attn_len (0 = none)
   int full;       // min_full_attn_seq_len
   int has_targets;
+  int simple;     // plain causal: no targets, no window, no contextual rows -> valid = (j <= i)
 
   HSTU_DEV int id_of(int pos) const {
     int id = ctx > 0 ? max(pos - ctx + 1, 0) : pos;
@@ -192,6 +193,7 @@ struct MaskCtx {
   // row position i (query), col position j (key); both < len
   HSTU_DEV bool valid(int i, int j) const { return valid_ids(i, j, id_of(i), id_of(j)); }
   HSTU_DEV bool valid_ids(int i, int j, int idi, int idj) const {
+    if (simple) return j <= i;
     const int d = idi - idj;
     bool m = (i == j) | (d > 0);
     if (win > 0) m = m & ((d <= win) | ((full > 0) & (idi >= max_id - full)));
@@ -236,6 +238,7 @@ HSTU_DEV MaskCtx make_mask_ctx(const HstuAttnParams& p, int b, int len) {
   if (m.ctx > 0) max_id = max_id - m.ctx + 1;
   if (m.has_targets) max_id -= (int)load_index(p.num_targets, b, p.targets_dtype);
   m.max_id = max_id;
+  m.simple = (!m.has_targets) && m.win == 0 && m.ctx == 0;
   return m;
 }
 
@@ -243,6 +246,24 @@ HSTU_DEV MaskCtx make_mask_ctx(const HstuAttnParams& p, int b, int len) {
 HSTU_DEV float fast_sigmoid(float s) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * s));
 }
+
+// Optional cycle-counter trace (debug builds with -DHSTU_TRACE only; see tools/trace_build.sh):
+// lane 0 of every wave of ONE workgroup appends s_memtime stamps to a global buffer.
+#ifdef HSTU_TRACE
+static __device__ unsigned long long* g_hstu_trace_fwd = nullptr;   // set by hstu_trace_set_fwd (trace builds only)
+#define HSTU_TRACE_DECL(ptr, on) unsigned long long* _trc = (unsigned long long*)(ptr); const bool _trc_on = (on); int _trc_i = 0
+#define HSTU_MARK(tag)                                                                       \
+  do {                                                                                       \
+    if (_trc_on && (threadIdx.x & 63) == 0 && _trc_i < 126) {                                \
+      _trc[(threadIdx.x >> 6) * 256 + 2 * _trc_i] = (unsigned long long)(tag);               \
+      _trc[(threadIdx.x >> 6) * 256 + 2 * _trc_i + 1] = __builtin_readcyclecounter();        \
+      ++_trc_i;                                                                              \
+    }                                                                                        \
+  } while (0)
+#else
+#define HSTU_TRACE_DECL(ptr, on)
+#define HSTU_MARK(tag)
+#endif
 
 // 16-byte global load / store helpers
 HSTU_DEV u32x4 gload16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }

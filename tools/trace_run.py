@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Run the traced backward kernel (tests/probe/libhstu_trace.so, built by tools/trace_build.sh)
+on the metric shape and print the per-wave phase timeline of one workgroup (cycles)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from generative_recommenders_amd import _lib as L
+L.LIB_PATH = os.path.join(ROOT, "tests", "probe", "libhstu_trace.so")
+from generative_recommenders_amd.ops import _launch
+
+dev = "cuda"
+H, d, B, N = 4, 128, 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 200
+lengths = torch.full((B,), N, dtype=torch.int64, device=dev)
+off = torch.zeros(B + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(lengths, 0)
+Lt = int(off[-1])
+fused = torch.empty(Lt, H, 3 * d, device=dev, dtype=torch.bfloat16).uniform_(-0.01, 0.01)
+q, k, v = torch.split(fused, [d, d, d], dim=-1)
+do = torch.randn(Lt, H, d, device=dev, dtype=torch.bfloat16)
+dfused = torch.empty_like(fused); dq, dk, dv = torch.split(dfused, [d, d, d], dim=-1)
+trace = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
+bp = L.HstuAttnBwdParams()
+_launch._fill_attn_params(bp.fwd, q, k, v, None, off, None, N, d ** -0.5, 1.0 / N, 0, 0, 0, 0)
+bp.dout, bp.dq, bp.dk, bp.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+bp.do_row_stride, bp.do_head_stride = do.stride(0), do.stride(1)
+for n, t in (("dq", dq), ("dk", dk), ("dv", dv)):
+    setattr(bp, n + "_row_stride", t.stride(0)); setattr(bp, n + "_head_stride", t.stride(1))
+bp.total_rows = Lt
+bp.workspace = trace.data_ptr()
+for _ in range(3):
+    L.check(L.lib().hstu_attn_bwd(C.byref(bp), torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
+def dump(t, names, waves):
+    t0 = min(int(t[w, 0, 1]) for w in range(8) if t[w, 0, 0])
+    for w in waves:
+        print(f"--- wave {w}")
+        prev = t0
+        for i in range(128):
+            tag, ts = int(t[w, i, 0]), int(t[w, i, 1])
+            if tag == 0:
+                break
+            print(f"  {names.get(tag, tag):>18s}  t={ts - t0:8d}  (+{ts - prev})")
+            prev = ts
+
+ftrace = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
+L.lib()
+import ctypes
+tl = ctypes.CDLL(L.LIB_PATH)
+tl.hstu_trace_set_fwd.argtypes = [ctypes.c_void_p]
+print("set fwd trace:", tl.hstu_trace_set_fwd(ftrace.data_ptr()))
+for _ in range(3):
+    _launch.attn_fwd(q, k, v, off, None, N, d ** -0.5, 1.0 / N)
+torch.cuda.synchronize()
+print("===== FORWARD (workgroup 4096)")
+dump(ftrace.cpu().view(8, 128, 2).numpy(), {1: "start", 2: "Q issued+done", 3: "tile0 staged", 10: "iter top (loads issued)",
+     11: "S done", 12: "elementwise done", 13: "PV done", 14: "next tile written", 15: "barrier passed", 20: "loop done",
+     21: "end"}, (0, 2, 3))
+print("===== BACKWARD (workgroup 4096)")
+t = trace.cpu().view(8, 128, 2).numpy()
+names = {1: "start", 2: "kv_loaded_issued", 3: "stage0_ready", 10: "step_begin", 11: "S,dP done", 12: "elementwise done",
+         13: "dV,dK done", 14: "publish done", 15: "barrier1 passed", 16: "stage written", 17: "phase2 done",
+         18: "barrier2 passed", 20: "loop done", 21: "end"}
+t0 = min(int(t[w, 0, 1]) for w in range(8) if t[w, 0, 0])
+for w in (0, 3, 6, 7):
+    print(f"--- wave {w}")
+    prev = t0
+    for i in range(128):
+        tag, ts = int(t[w, i, 0]), int(t[w, i, 1])
+        if tag == 0:
+            break
+        print(f"  {names.get(tag, tag):>18s}  t={ts - t0:8d}  (+{ts - prev})")
+        prev = ts
