@@ -219,23 +219,14 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int it_lo = (mc.ctx > 0) ? 0 : kt0;          // contextual rows (id 0) see every key
   const int it_hi = (len + 31) >> 5;
 
-  // ---- resident K/V block: all loads in flight at once (registers are free before the
-  // accumulators become live), then written to LDS
-  for (int wb = 0; wb < nw; wb += 4) {   // 4 tiles (8 loads of 16 B per thread) in flight per round
-    u32x4 kr[4][C::NQU], vr[4][C::NOU];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (wb + j < nw && kb0 + 32 * (wb + j) < len) {
-        tile_gload<T, DQK, C::NQU, kBwdThreads>(kr[j], kbase, k_rs, kb0 + 32 * (wb + j), len, p.dqk, tid);
-        tile_gload<T, DV, C::NOU, kBwdThreads>(vr[j], vbase, v_rs, kb0 + 32 * (wb + j), len, p.dv, tid);
-      }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (wb + j < nw && kb0 + 32 * (wb + j) < len) {
-        tile_lds_write<T, DQK, C::NQU, kBwdThreads>(kr[j], smem + (wb + j) * C::PAIR, kb0 + 32 * (wb + j), len, p.dqk, tid);
-        tile_lds_write<T, DV, C::NOU, kBwdThreads>(vr[j], smem + (wb + j) * C::PAIR + C::KT, kb0 + 32 * (wb + j), len, p.dv, tid);
-      }
-  }
+  // ---- resident K/V block by LDS-DMA: every 1 KiB chunk of the block is in flight at once, no
+  // registers and no ds_write involved (rows past len receive a clamped copy: masked, never used)
+  for (int w2 = 0; w2 < nw; ++w2)
+    if (kb0 + 32 * w2 < len) {
+      char* dst = smem + w2 * C::PAIR;
+      tile_dma<T, DQK>(dst, kbase, k_rs, kb0 + 32 * w2, len, p.dqk, wave, kBwdWaves, lane);
+      tile_dma<T, DV>(dst + C::KT, vbase, v_rs, kb0 + 32 * w2, len, p.dv, wave, kBwdWaves, lane);
+    }
   HSTU_MARK(2);
   u32x4 qreg[C::NQU], oreg[C::NOU];
   tile_gload<T, DQK, C::NQU, kBwdThreads>(qreg, qbase, q_rs, (it_hi - 1) * 32, len, p.dqk, tid);

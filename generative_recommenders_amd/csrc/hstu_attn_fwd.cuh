@@ -79,6 +79,33 @@ HSTU_DEV void tile_lds_write(const u32x4 (&reg)[NU], char* tile, int row0, int l
   }
 }
 
+// LDS-DMA variant (global_load_lds_dwordx4): wave `wave` of `nwaves` moves 1 KiB chunks of a
+// [32][D] tile from global memory straight into LDS -- no VGPRs, no ds_write, completion counted
+// by vmcnt (the compiler waits for it before the next __syncthreads()).  The hardware writes lane
+// l's 16 bytes to (wave-uniform base) + 16 l, so the XOR swizzle of tile_off is applied on the
+// SOURCE side: the lane that fills physical slot s of a row fetches logical unit s ^ swizzle(row).
+// No zero fill is possible: rows past `len` / columns past the real head dim receive a clamped
+// (valid, finite) copy, so callers must MASK such keys instead of relying on zeros.
+template <typename T, int D>
+HSTU_DEV void tile_dma(char* tile, const char* base, int64_t row_stride_bytes, int row0, int len, int real_d,
+                       int wave, int nwaves, int lane) {
+  constexpr int UPR = D * Elem<T>::kBytes / 16;
+  constexpr int EPU = 16 / Elem<T>::kBytes;
+  constexpr int NCH = 32 * UPR / 64;   // 1 KiB chunks per tile
+  for (int c = wave; c < NCH; c += nwaves) {
+    const int pidx = c * 64 + lane;
+    const int row = pidx / UPR, slot = pidx % UPR;
+    int unit;
+    if constexpr (UPR >= 16) unit = slot ^ (row & 15);
+    else unit = slot ^ ((row / (16 / UPR)) & (UPR - 1));
+    const int grow = min(row0 + row, len - 1);
+    const int gunit = (unit * EPU < real_d) ? unit : 0;
+    const char* g = base + (int64_t)grow * row_stride_bytes + gunit * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(tile + c * 1024), 16, 0, 0);
+  }
+}
+
 // Row fragment straight from global memory (unconditional, caller clamps the address):
 // raw 16-byte pieces first, converted / zeroed by finish_row_frag once all are in flight.
 template <typename T> struct RawFrag { u32x4 x0, x1; };

@@ -201,12 +201,12 @@ struct MaskCtx {
     return m;
   }
   // Is EVERY (i, j) with i in [i0, i0+ni), j in [j0, j0+nj), i,j < len valid?  (sufficient
-  // condition; such tiles skip the per-element mask.  Rows/cols >= len need no mask either:
-  // their q / k / v rows are zero-filled, so silu(0) = 0 and 0 * 0 = 0.)
+  // condition; such tiles skip the per-element mask.  Query rows >= len need no mask: their
+  // q / dO rows are zero-filled by the register staging path, so silu(0) = 0 and 0 * x = 0.)
   HSTU_DEV bool pair_fully_valid(int i0, int ni, int j0, int nj) const {
-    if (i0 >= len || j0 >= len) return false;
+    if (i0 >= len || j0 + nj > len) return false;   // key rows past len may hold garbage (LDS-DMA): mask them
     const int i1 = min(i0 + ni, len) - 1;
-    const int j1 = min(j0 + nj, len) - 1;
+    const int j1 = j0 + nj - 1;
     if (id_of(i0) - id_of(j1) < 1) return false;          // every pair strictly causal
     if (win > 0 && id_of(i1) - id_of(j0) > win) return false;  // every pair inside the window
     return true;

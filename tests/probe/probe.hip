@@ -42,6 +42,21 @@ __global__ void probe_tr_read(const int* addr, int16_t* out) {
   for (int j = 0; j < 4; ++j) out[l * 4 + j] = t[j];
 }
 
+typedef uint32_t pu32x4 __attribute__((ext_vector_type(4)));
+// each lane copies 16 B from src[perm[lane]] (16-byte units) into LDS via LDS-DMA; then the LDS
+// image (64 units) is written back linearly to out.
+__global__ void probe_glds(const pu32x4* src, const int* perm, pu32x4* out) {
+  __shared__ __attribute__((aligned(16))) pu32x4 lds[256];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = pu32x4{0xdeadu, 0, 0, 0};
+  __syncthreads();
+  const pu32x4* g = src + perm[l] + 64 * w;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)(lds + 64 * w), 16, 0, 0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) out[i] = lds[i];
+}
+
 extern "C" {
 int probe_run_mfma_bf16(const void* A, const void* B, void* C, void* stream) {
   hipLaunchKernelGGL(probe_mfma_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (float*)C);
@@ -53,6 +68,10 @@ int probe_run_mfma_f32(const void* A, const void* B, void* C, void* stream) {
 }
 int probe_run_tr_read(const void* addr, void* out, void* stream) {
   hipLaunchKernelGGL(probe_tr_read, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)addr, (int16_t*)out);
+  return (int)hipGetLastError();
+}
+int probe_run_glds(const void* src, const void* perm, void* out, void* stream) {
+  hipLaunchKernelGGL(probe_glds, dim3(1), dim3(256), 0, (hipStream_t)stream, (const pu32x4*)src, (const int*)perm, (pu32x4*)out);
   return (int)hipGetLastError();
 }
 }

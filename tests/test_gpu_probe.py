@@ -107,3 +107,19 @@ def test_ds_read_tr16_b64_semantics():
         _dump("probe_tr_read_got.npy", got)
         _dump("probe_tr_read_addr.npy", addr)
     assert np.array_equal(got, exp)
+
+
+def test_lds_dma_lane_linear_destination():
+    """global_load_lds_dwordx4: lane l of a wave writes its 16 bytes to (wave-uniform LDS base)
+    + 16*l, whatever global address it read from (the source address is per lane)."""
+    lib = _probe()
+    g = torch.Generator().manual_seed(5)
+    src = torch.randint(0, 2**31 - 1, (256 + 64, 4), generator=g, dtype=torch.int32).cuda()
+    perm = torch.randperm(64, generator=g).to(torch.int32).cuda()
+    out = torch.zeros(256, 4, dtype=torch.int32, device="cuda")
+    assert lib.probe_run_glds(C.c_void_p(src.data_ptr()), C.c_void_p(perm.data_ptr()), C.c_void_p(out.data_ptr()), _stream()) == 0
+    torch.cuda.synchronize()
+    exp = torch.stack([src[perm[l].item() + 64 * w] for w in range(4) for l in range(64)])
+    if not torch.equal(out, exp):
+        _dump("probe_glds_got.npy", out.cpu().numpy())
+    assert torch.equal(out, exp)
