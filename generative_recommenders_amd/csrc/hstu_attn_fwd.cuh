@@ -41,7 +41,13 @@ struct FwdCfg {
   static constexpr int DB = DV / 32;             // 32-wide output blocks
   static constexpr int NKU = (32 * UPR_K + kFwdThreads - 1) / kFwdThreads;  // staged units / thread
   static constexpr int NVU = (32 * UPR_V + kFwdThreads - 1) / kFwdThreads;
-  static constexpr int SMEM = 2 * STAGE;
+  // K/V ring filled by LDS-DMA.  Counted vmcnt waits need every wave to issue the same number of
+  // DMA instructions per tile (whole multiples of the 4 waves); otherwise depth 2 with full drains.
+  static constexpr int NCH_K = 32 * UPR_K / 64, NCH_V = 32 * UPR_V / 64;
+  static constexpr bool COUNTED = (NCH_K % 4 == 0) && (NCH_V % 4 == 0);
+  static constexpr int PER_TILE = NCH_K / 4 + NCH_V / 4;      // DMA instructions per wave per tile
+  static constexpr int NS = (COUNTED && STAGE <= 16384) ? 3 : 2;  // ring depth (= tiles in flight + 1)
+  static constexpr int SMEM = NS * STAGE;
 };
 
 // Cooperative global -> register load of one [32][D] tile and the matching register -> LDS
@@ -111,26 +117,29 @@ HSTU_DEV void tile_dma(char* tile, const char* base, int64_t row_stride_bytes, i
 template <typename T> struct RawFrag { u32x4 x0, x1; };
 
 template <typename T>
-HSTU_DEV RawFrag<T> global_row_frag_issue(const char* row_ptr, int e0) {
+HSTU_DEV RawFrag<T> global_row_frag_issue(const char* row_ptr, int e0, bool second_ok) {
   RawFrag<T> r;
   if constexpr (Elem<T>::kBytes == 2) {
     r.x0 = gload16(row_ptr + e0 * 2);
     r.x1 = r.x0;
   } else {
     r.x0 = gload16(row_ptr + e0 * 4);
-    r.x1 = gload16(row_ptr + e0 * 4 + 16);
+    r.x1 = gload16(row_ptr + e0 * 4 + (second_ok ? 16 : 0));   // never read past the row
   }
   return r;
 }
 
+// `ok1` covers the second 16-byte piece of an fp32 fragment (the real head dim is a multiple of
+// 4 elements only, so a fragment may straddle it; the other operand is NOT zero padded when it
+// comes through LDS-DMA, so this one must be).
 template <typename T>
-HSTU_DEV typename Elem<T>::Frag finish_row_frag(const RawFrag<T>& r, bool ok) {
+HSTU_DEV typename Elem<T>::Frag finish_row_frag(const RawFrag<T>& r, bool ok, bool ok1) {
   typename Elem<T>::Frag f;
   const u32x4 z = {0u, 0u, 0u, 0u};
   if constexpr (Elem<T>::kBytes == 2) {
     f.v = __builtin_bit_cast(typename Elem<T>::vec8, ok ? r.x0 : z);
   } else {
-    f32x4 a = __builtin_bit_cast(f32x4, ok ? r.x0 : z), b = __builtin_bit_cast(f32x4, ok ? r.x1 : z);
+    f32x4 a = __builtin_bit_cast(f32x4, ok ? r.x0 : z), b = __builtin_bit_cast(f32x4, (ok && ok1) ? r.x1 : z);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
   }
@@ -216,12 +225,12 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
 #pragma unroll
     for (int kg = 0; kg < C::KG; ++kg) {
       const int e0 = hf * (DQK / 2) + kg * 8;
-      raw[kg] = global_row_frag_issue<T>(qrow, e0 < p.dqk ? e0 : 0);
+      raw[kg] = global_row_frag_issue<T>(qrow, e0 < p.dqk ? e0 : 0, e0 + 4 < p.dqk);
     }
 #pragma unroll
     for (int kg = 0; kg < C::KG; ++kg) {
       const int e0 = hf * (DQK / 2) + kg * 8;
-      qf[kg] = finish_row_frag<T>(raw[kg], row_ok && e0 < p.dqk);
+      qf[kg] = finish_row_frag<T>(raw[kg], row_ok && e0 < p.dqk, e0 + 4 < p.dqk);
     }
   }
 
@@ -236,26 +245,32 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 
-  u32x4 kreg[C::NKU], vreg[C::NVU];
-  if (ntiles > 0) {
-    tile_gload<T, DQK, C::NKU, kFwdThreads>(kreg, kbase, k_rs, kv_lo, len, p.dqk, tid);
-    tile_gload<T, DV, C::NVU, kFwdThreads>(vreg, vbase, v_rs, kv_lo, len, p.dv, tid);
-    tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, smem, kv_lo, len, p.dqk, tid);
-    tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, smem + C::KT, kv_lo, len, p.dv, tid);
-  }
-  __syncthreads();
+  // ---- K/V tiles stream through an NS-deep LDS ring filled by LDS-DMA: tiles t+1 .. t+NS-1 are in
+  // flight while tile t is computed; one raw barrier per tile, loads are never drained in the loop
+  auto issue_tile = [&](int t) {
+    char* st = smem + (t % C::NS) * C::STAGE;
+    tile_dma<T, DQK>(st, kbase, k_rs, kv_lo + 32 * t, len, p.dqk, wave, 4, lane);
+    tile_dma<T, DV>(st + C::KT, vbase, v_rs, kv_lo + 32 * t, len, p.dv, wave, 4, lane);
+  };
+  for (int t = 0; t < C::NS - 1 && t < ntiles; ++t) issue_tile(t);
   HSTU_MARK(3);
 
   for (int t = 0; t < ntiles; ++t) {
     const int j0 = kv_lo + (t << 5);
-    const bool more = t + 1 < ntiles;
-    if (more) {  // issue next tile's global loads; they land while this tile is computed
-      tile_gload<T, DQK, C::NKU, kFwdThreads>(kreg, kbase, k_rs, j0 + 32, len, p.dqk, tid);
-      tile_gload<T, DV, C::NVU, kFwdThreads>(vreg, vbase, v_rs, j0 + 32, len, p.dv, tid);
+    // tile t has landed once at most (tiles issued after it) * PER_TILE DMA instructions are pending
+    if constexpr (C::COUNTED) {
+      const int newer = min(C::NS - 2, ntiles - 1 - t);     // tiles issued after tile t so far
+      if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();   // every wave's chunks of tile t landed; stage (t-1) % NS is free
+    asm volatile("" ::: "memory");
+    if (t + C::NS - 1 < ntiles) issue_tile(t + C::NS - 1);
     HSTU_MARK(10);
     if (wave_active && mc.pair_may_be_active(r0 + i_shift, 32, j0, 32)) {
-      const char* Kt = smem + (t & 1) * C::STAGE;
+      const char* Kt = smem + (t % C::NS) * C::STAGE;
       const char* Vt = Kt + C::KT;
       f32x16 s, s1;   // two accumulators halve the dependent-MFMA chain of the QK^T contraction
 #pragma unroll
@@ -309,15 +324,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         }
       }
     }
-    HSTU_MARK(13);
-    if (more) {
-      char* nxt = smem + ((t + 1) & 1) * C::STAGE;
-      tile_lds_write<T, DQK, C::NKU, kFwdThreads>(kreg, nxt, j0 + 32, len, p.dqk, tid);
-      tile_lds_write<T, DV, C::NVU, kFwdThreads>(vreg, nxt + C::KT, j0 + 32, len, p.dv, tid);
-    }
     HSTU_MARK(14);
-    __syncthreads();
-    HSTU_MARK(15);
   }
   HSTU_MARK(20);
 
