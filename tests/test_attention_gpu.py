@@ -305,3 +305,44 @@ def test_errors():
     big = torch.zeros(4, 2, 256, device=DEV, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="not instantiated"):
         _ops().hstu_mha(4, 1.0, big, big, big, off)
+
+
+# ------------------------------------------------------------------ torch.ops.hstu.* operator seam
+def test_torch_library_operator_seam():
+    """The reference's `hstu::` schemas (flash_api.cpp:275-352, cpp_ops.cpp:94-102) dispatch to the
+    HIP library and give the same results as the function API."""
+    from generative_recommenders_amd.ops import torch_library
+
+    torch_library.register()
+    torch_library.register()  # idempotent
+    rng = np.random.default_rng(77)
+    c = _make_case(rng, 4, 2, 90, 8, 64, 64, True, True, 0)
+    off = torch.from_numpy(c["off"]).to(DEV)
+    nt = torch.from_numpy(c["nt"]).to(DEV)
+    q, k, v = (_t(c[x], torch.bfloat16, True) for x in ("q", "k", "v"))
+    out = torch.ops.hstu.hstu_mha(c["N"], c["alpha"], q, k, v, off, True, nt, None, c["w"], 0, 0, None, None, None,
+                                  False, False, 0)
+    ref = _ops().hstu_mha(c["N"], c["alpha"], q.detach(), k.detach(), v.detach(), off, num_targets=nt, max_attn_len=c["w"])
+    assert torch.equal(out, ref)
+    do = _t(c["dout"], torch.bfloat16)
+    out.backward(do)
+    q2, k2, v2 = (_t(c[x], torch.bfloat16, True) for x in ("q", "k", "v"))
+    _ops().hstu_mha(c["N"], c["alpha"], q2, k2, v2, off, num_targets=nt, max_attn_len=c["w"]).backward(do)
+    assert torch.equal(q.grad, q2.grad) and torch.equal(k.grad, k2.grad) and torch.equal(v.grad, v2.grad)
+    # fwd / bwd entry points with caller-allocated gradients (strided views of one buffer)
+    o2 = torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach(), k.detach(), v.detach(), off, True, nt, None, c["w"],
+                                     0, 0, None, None, None, 0)
+    assert torch.equal(o2, ref)
+    buf = torch.zeros(q.shape[0], q.shape[1], 3 * 64, device=DEV, dtype=torch.bfloat16)
+    dq, dk, dv = torch.split(buf, [64, 64, 64], dim=-1)
+    res = torch.ops.hstu.hstu_mha_bwd(c["N"], c["alpha"], do, q.detach(), k.detach(), v.detach(), dq, dk, dv, off, True,
+                                      nt, None, c["w"], 0, 0, False, False, 0)
+    assert torch.equal(res[0], q2.grad) and torch.equal(dk, k2.grad) and torch.equal(dv, v2.grad)
+    x = torch.tensor([3, 0, 5], device=DEV)
+    assert torch.ops.hstu.complete_cumsum(x).tolist() == [0, 3, 3, 8]
+    assert torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach().to("meta"), k.detach().to("meta"),
+                                       v.detach().to("meta"), None, True, None, None, 0, 0, 0, None, None, None,
+                                       0).shape == ref.shape
+    with pytest.raises(RuntimeError, match="attn_scale"):
+        torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach(), k.detach(), v.detach(), off, True, nt,
+                                    torch.ones(1, device=DEV), 0, 0, 0, None, None, None, 0)
