@@ -263,6 +263,16 @@ def main():
         "roofline_fwd_bwd": {"achieved": att["both_gbps"], "unit": "GB/s", "frac": att["both_gbps"] / HBM_PEAK_GBPS,
                              "tflops_causal_model": att["tflops"]},
     }
+    # HBM traffic from the PMC passes (collected separately with tools/prof_pmc.sh on this same
+    # workload and committed under profiles/; counters cannot be read from inside the process)
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if args.workload == "M-full" and args.users_per_gpu == 8192:
+            res["roofline"]["traffic"] = tr["bwd"]["hbm_bytes_per_launch"]
+            res["roofline"]["traffic_over_algorithmic"] = tr["bwd"]["hbm_bytes_per_launch"] / att["bwd_bytes"]
+            res["roofline_fwd"]["traffic"] = tr["fwd"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         try:
             res["measured_copy_GBps"] = copy_bandwidth(device)
