@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime ou
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhstu_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
 HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
@@ -40,6 +40,8 @@ class HstuAttnParams(C.Structure):
         ("alpha", C.c_float), ("scale", C.c_float),
         ("max_attn_len", C.c_int32), ("contextual_seq_len", C.c_int32), ("min_full_attn_seq_len", C.c_int32),
         ("dtype", C.c_int32), ("offsets_dtype", C.c_int32), ("targets_dtype", C.c_int32),
+        ("pos_w", C.c_void_p), ("ts_w", C.c_void_p), ("timestamps", C.c_void_p),
+        ("ts_row_stride", C.c_int64), ("num_buckets", C.c_int32), ("bucket_div", C.c_float),
     ]
 
 
@@ -52,6 +54,7 @@ class HstuAttnBwdParams(C.Structure):
         ("dk_row_stride", C.c_int64), ("dk_head_stride", C.c_int64),
         ("dv_row_stride", C.c_int64), ("dv_head_stride", C.c_int64),
         ("workspace", C.c_void_p), ("total_rows", C.c_int64),
+        ("dpos_w", C.c_void_p), ("dts_w", C.c_void_p),
     ]
 
 

@@ -5,19 +5,40 @@
 
 namespace hstu {
 
-template <typename T, int DQK, int DV>
+template <typename T, int DQK, int DV, bool BIAS = false>
 static int launch_fwd_inst(const HstuAttnParams& p, hipStream_t st) {
   using C = FwdCfg<T, DQK, DV>;
   const int q_rows = p.delta_q > 0 ? p.delta_q : p.max_seq_len;
   const int nqb = (q_rows + kFwdRowsPerBlock - 1) / kFwdRowsPerBlock;
   const int groups = (p.batch * p.heads + 7) / 8;
-  auto kern = hstu_attn_fwd_kernel<T, DQK, DV>;
+  auto kern = hstu_attn_fwd_kernel<T, DQK, DV, BIAS>;
   if (C::SMEM > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_fwd: cannot reserve %d bytes of LDS: %s", C::SMEM, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(kern, dim3(groups * 8 * nqb), dim3(kFwdThreads), C::SMEM, st, p, nqb);
   return check_launch("hstu_attn_fwd");
+}
+
+template <typename T, int DQK, int DV, bool BIAS>
+static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st);
+
+template <typename T>
+static int launch_fwd_bias_dtype(const HstuAttnParams& p, hipStream_t st) {
+  const int a = pad_head_dim(p.dqk), v = pad_head_dim(p.dv);
+#define CASE(A) if (a == A && v == A) return launch_fwd_inst<T, A, A, true>(p, st);
+  CASE(32) CASE(64) CASE(128)
+#undef CASE
+  return set_error(HSTU_EUNSUPPORTED, "hstu_attn_fwd: relative-bias attention is instantiated for dqk == dv in {32, 64, 128} (got %d, %d)", p.dqk, p.dv);
+}
+
+template <typename T>
+static int launch_bwd_bias_dtype(const HstuAttnBwdParams& bp, hipStream_t st) {
+  const int a = pad_head_dim(bp.fwd.dqk), v = pad_head_dim(bp.fwd.dv);
+#define CASE(A) if (a == A && v == A) return launch_bwd_inst<T, A, A, true>(bp, st);
+  CASE(32) CASE(64) CASE(128)
+#undef CASE
+  return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd: relative-bias attention is instantiated for dqk == dv in {32, 64, 128} (got %d, %d)", bp.fwd.dqk, bp.fwd.dv);
 }
 
 template <typename T>
@@ -29,36 +50,52 @@ static int launch_fwd_dtype(const HstuAttnParams& p, hipStream_t st) {
   return set_error(HSTU_EUNSUPPORTED, "hstu_attn_fwd: head dims (%d, %d) not instantiated", p.dqk, p.dv);
 }
 
+static inline int bias_hist_bytes(const HstuAttnParams& p) {
+  return p.pos_w ? ((2 * p.max_seq_len + p.num_buckets) * 4 + 15) / 16 * 16 : 0;
+}
+
 template <typename T, int DQK, int DV>
-static int bwd_tiles_inst(int max_seq_len) {
+static int bwd_tiles_inst(int max_seq_len, int extra_lds) {
   using C = BwdCfg<T, DQK, DV>;
-  int nw = C::max_tiles(kLdsBudget);
+  int nw = C::max_tiles(kLdsBudget - extra_lds);
   const int need = (max_seq_len + 31) / 32;
   if (need < nw) nw = need;
   return nw < 1 ? 1 : nw;
 }
 
-template <typename T, int DQK, int DV>
+template <typename T, int DQK, int DV, bool BIAS>
 static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   using C = BwdCfg<T, DQK, DV>;
   const HstuAttnParams& p = bp.fwd;
-  const int nw = bwd_tiles_inst<T, DQK, DV>(p.max_seq_len);
+  const int hist = bias_hist_bytes(p);
+  const int nw = bwd_tiles_inst<T, DQK, DV>(p.max_seq_len, hist);
   const int nkb = (p.max_seq_len + 32 * nw - 1) / (32 * nw);
   const int groups = (p.batch * p.heads + 7) / 8;
-  const int smem = C::smem_bytes(nw);
-  auto kern = hstu_attn_bwd_kernel<T, DQK, DV>;
+  const int nblocks = groups * 8 * nkb;
+  const int smem = C::smem_bytes(nw, hist);
+  if (smem > kLdsBudget) return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd: max_seq_len %d needs %d bytes of LDS for the bias histograms", p.max_seq_len, smem);
+  auto kern = hstu_attn_bwd_kernel<T, DQK, DV, BIAS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
   }
+  // workspace layout: [fp32 dq accumulator (several key blocks only)] [bias-gradient partial rows]
   float* acc = nullptr;
+  size_t acc_bytes = 0;
   if (nkb > 1) {
     acc = (float*)bp.workspace;
-    const size_t bytes = (size_t)bp.total_rows * p.heads * p.dqk * sizeof(float);
-    hipError_t e = hipMemsetAsync(acc, 0, bytes, st);
+    acc_bytes = ((size_t)bp.total_rows * p.heads * p.dqk * sizeof(float) + 255) / 256 * 256;
+    hipError_t e = hipMemsetAsync(acc, 0, acc_bytes, st);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(groups * 8 * nkb), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc);
+  float* partial = nullptr;
+  const int hw = 2 * p.max_seq_len + p.num_buckets;
+  if (BIAS) {
+    partial = (float*)((char*)bp.workspace + acc_bytes);
+    hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblocks * hw * sizeof(float), st);
+    if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial);
   if (int e = check_launch("hstu_attn_bwd")) return e;
   if (nkb > 1) {
     const int64_t n = bp.total_rows * p.heads * (int64_t)p.dqk;
@@ -66,24 +103,25 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(hstu_dq_convert_kernel<T>, dim3(blocks), dim3(256), 0, st, acc, bp.dq, bp.total_rows, p.heads,
                        p.dqk, bp.dq_row_stride, bp.dq_head_stride);
-    return check_launch("hstu_attn_bwd(dq convert)");
+    if (int e = check_launch("hstu_attn_bwd(dq convert)")) return e;
   }
+  if (BIAS) return launch_bias_grad_reduce(partial, nblocks, hw, 2 * p.max_seq_len - 1, bp.dpos_w, bp.dts_w, st);
   return HSTU_OK;
 }
 
 template <typename T>
 static int launch_bwd_dtype(const HstuAttnBwdParams& bp, hipStream_t st) {
   const int a = pad_head_dim(bp.fwd.dqk), v = pad_head_dim(bp.fwd.dv);
-#define CASE(A, V) if (a == A && v == V) return launch_bwd_inst<T, A, V>(bp, st);
+#define CASE(A, V) if (a == A && v == V) return launch_bwd_inst<T, A, V, false>(bp, st);
   CASE(32, 32) CASE(32, 64) CASE(32, 128) CASE(64, 32) CASE(64, 64) CASE(64, 128) CASE(128, 32) CASE(128, 64) CASE(128, 128)
 #undef CASE
   return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd: head dims (%d, %d) not instantiated", bp.fwd.dqk, bp.fwd.dv);
 }
 
 template <typename T>
-static int bwd_tiles_dtype(int dqk, int dv, int max_seq_len) {
+static int bwd_tiles_dtype(int dqk, int dv, int max_seq_len, int extra_lds) {
   const int a = pad_head_dim(dqk), v = pad_head_dim(dv);
-#define CASE(A, V) if (a == A && v == V) return bwd_tiles_inst<T, A, V>(max_seq_len);
+#define CASE(A, V) if (a == A && v == V) return bwd_tiles_inst<T, A, V>(max_seq_len, extra_lds);
   CASE(32, 32) CASE(32, 64) CASE(32, 128) CASE(64, 32) CASE(64, 64) CASE(64, 128) CASE(128, 32) CASE(128, 64) CASE(128, 128)
 #undef CASE
   return 0;

@@ -43,6 +43,12 @@ static int validate_attn(const HstuAttnParams& p, const char* who) {
   if (p.max_attn_len < 0 || p.contextual_seq_len < 0 || p.min_full_attn_seq_len < 0)
     return set_error(HSTU_EINVAL, "%s: negative mask parameter", who);
   if (p.delta_q < 0) return set_error(HSTU_EINVAL, "%s: negative delta_q", who);
+  if (p.pos_w) {
+    if (p.delta_q != 0) return set_error(HSTU_EUNSUPPORTED, "%s: relative bias with delta_q is not supported", who);
+    if ((p.ts_w == nullptr) != (p.timestamps == nullptr)) return set_error(HSTU_EINVAL, "%s: ts_w and timestamps must be given together", who);
+    if (p.ts_w && (p.num_buckets <= 0 || !(p.bucket_div > 0.f) || p.ts_row_stride < p.max_seq_len))
+      return set_error(HSTU_EINVAL, "%s: bad bucket parameters / timestamp stride", who);
+  }
   return HSTU_OK;
 }
 
@@ -87,6 +93,8 @@ int hstu_attn_bwd(const HstuAttnBwdParams* p, void* stream) {
     if ((s * eb) % 16) return set_error(HSTU_EINVAL, "hstu_attn_bwd: gradient rows must be 16-byte aligned (stride %lld elements)", (long long)s);
   if (((uintptr_t)p->dout | (uintptr_t)p->dq | (uintptr_t)p->dk | (uintptr_t)p->dv) & 15)
     return set_error(HSTU_EINVAL, "hstu_attn_bwd: gradient base pointers must be 16-byte aligned");
+  if (p->fwd.pos_w && (!p->dpos_w || (p->fwd.ts_w && !p->dts_w)))
+    return set_error(HSTU_EINVAL, "hstu_attn_bwd: dpos_w / dts_w outputs are required with a relative bias");
   if (p->fwd.batch == 0 || p->total_rows == 0) return HSTU_OK;
   if (attn_bwd_workspace_bytes(*p) > 0 && !p->workspace)
     return set_error(HSTU_EINVAL, "hstu_attn_bwd: this shape needs %zu bytes of workspace", attn_bwd_workspace_bytes(*p));

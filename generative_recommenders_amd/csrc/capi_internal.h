@@ -15,8 +15,17 @@ int launch_attn_fwd_f32(const HstuAttnParams& p, hipStream_t st);
 int launch_attn_bwd_bf16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_f16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_f32(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_fwd_bias_bf16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_fwd_bias_f16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_fwd_bias_f32(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_bwd_bias_bf16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_bias_f16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_bias_f32(const HstuAttnBwdParams& p, hipStream_t st);
+// sums the per-workgroup bias-gradient rows: partial (rows, width) -> dpos_w (npos), dts_w (width - npos)
+int launch_bias_grad_reduce(const float* partial, int rows, int width, int npos, float* dpos_w, float* dts_w,
+                            hipStream_t st);
 size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& p);
-int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len);
+int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int extra_lds);
 
 inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }
 constexpr int kLdsBudget = 160 * 1024;

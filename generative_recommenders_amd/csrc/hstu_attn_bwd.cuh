@@ -51,7 +51,7 @@ struct BwdCfg {
   static constexpr int DBV = DV / 32;
   static constexpr int NQU = (32 * UPR_K + kBwdThreads - 1) / kBwdThreads;
   static constexpr int NOU = (32 * UPR_V + kBwdThreads - 1) / kBwdThreads;
-  static constexpr int smem_bytes(int nw) { return nw * PAIR + PAIR + 2 * nw * DSBUF; }
+  static constexpr int smem_bytes(int nw, int extra = 0) { return nw * PAIR + PAIR + 2 * nw * DSBUF + extra; }
   // at most 7 key tiles per block: the 8th wave never owns a tile, so every step has a
   // helper wave for the dQ GEMM of the previous step
   static constexpr int max_tiles(int lds_budget) {
@@ -170,9 +170,9 @@ HSTU_DEV void bwd_dq_tile(const HstuAttnBwdParams& bp, const MaskCtx& mc, const 
     bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, lane);
 }
 
-template <typename T, int DQK, int DV>
+template <typename T, int DQK, int DV, bool BIAS = false>
 __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAttnBwdParams bp, int nkb, int nw,
-                                                                    float* dq_accum) {
+                                                                    float* dq_accum, float* bias_partial) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -203,6 +203,15 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   char* const dsbuf = stage + C::PAIR;               // 2 x nw buffers of [32 keys][32 q] (double buffered)
   const int k0w = kb0 + 32 * wave;                   // first key of this wave's tile
   const bool tile_owner = wave < nw && k0w < len;
+  // research-path bias: per-workgroup fp32 histograms of dS' over (j - i) and over the time bucket,
+  // flushed to this workgroup's row of `bias_partial` and summed by a second kernel
+  BiasCtx bc;
+  float* const hpos = (float*)(dsbuf + 2 * nw * C::DSBUF);
+  float* const hts = hpos + (2 * p.max_seq_len - 1);
+  if constexpr (BIAS) {
+    bc = make_bias_ctx(p, b);
+    for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) hpos[i] = 0.f;
+  }
 
   const char* qbase = (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
   const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
@@ -250,6 +259,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int key = k0w + n32;
   const bool key_ok = tile_owner && key < len;
   const int key_id = mc.id_of(key);
+  int64_t t_k = 0;
+  if constexpr (BIAS) t_k = bc.ts_at(key);
   // last (smallest) query tile this owner takes part in: its diagonal, or tile 0 with contextual rows
   const int my_last_it = (mc.ctx > 0) ? it_lo : max(it_lo, kt0 + wave);
 
@@ -294,10 +305,17 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {
         float pv[8], dsv[8];
+        int pidx[8], bkt[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int r = 8 * h8 + j;
-          const float x = s[r] * p.alpha;
+          float x = s[r] * p.alpha;
+          if constexpr (BIAS) {
+            const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            pidx[j] = bc.pos_index(qi, key);
+            bkt[j] = bc.bucket(bc.ts_at(qi + 1), t_k);
+            x += bc.value(pidx[j], bkt[j]);
+          }
           const float sg = fast_sigmoid(x);
           pv[j] = x * sg;
           dsv[j] = dp[r] * sg * (1.f + x * (1.f - sg));
@@ -319,6 +337,23 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
             const bool ok = key_ok & (qi < len) & mc.valid_ids(qi, key, mc.id_of(qi), key_id);
             pv[j] = ok ? pv[j] : 0.f;
             dsv[j] = ok ? dsv[j] : 0.f;
+          }
+        }
+        if constexpr (BIAS) {
+          // d bias = dS (summed over heads / users later); masked-out elements carry exact zeros
+          if (mode == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              atomicAdd(hpos + pidx[j], dsv[j]);
+              if (bc.ts_w) atomicAdd(hts + bkt[j], dsv[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (dsv[j] != 0.f) {
+                atomicAdd(hpos + pidx[j], dsv[j]);
+                if (bc.ts_w) atomicAdd(hts + bkt[j], dsv[j]);
+              }
           }
         }
         pb[h8] = E::pack8(pv);
@@ -391,6 +426,10 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
     bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_prev, nw, kb0, it_lo << 5, wave, 1, off0, hd, ds_scale, dq_accum, lane);
   }
   HSTU_MARK(21);
+  if constexpr (BIAS) {
+    float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
+    for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) row[i] = hpos[i] * p.scale;
+  }
   // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv
   if (key_ok) {
       char* dkrow = (char*)bp.dk + ((off0 + key) * bp.dk_row_stride + (int64_t)hd * bp.dk_head_stride) * C::EB;

@@ -159,7 +159,7 @@ HSTU_DEV void store4(char* row_ptr, int d0, float x0, float x1, float x2, float 
   }
 }
 
-template <typename T, int DQK, int DV>
+template <typename T, int DQK, int DV, bool BIAS = false>
 __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb) {
   using C = FwdCfg<T, DQK, DV>;
   using E = Elem<T>;
@@ -201,6 +201,12 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   const int qi = my_row + i_shift;               // logical position of this lane's query
 
   const int qi_id = mc.id_of(qi);
+  BiasCtx bc;
+  int64_t t_q1 = 0;
+  if constexpr (BIAS) {
+    bc = make_bias_ctx(p, b);
+    t_q1 = bc.ts_at(qi + 1);   // the row uses the NEXT item's timestamp
+  }
 
   // ---- key range visited by this workgroup (conservative; the per-element mask is exact)
   const int i_first = q0 + i_shift;
@@ -293,7 +299,12 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         float pv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float x = s[8 * h8 + j] * p.alpha;
+          float x = s[8 * h8 + j] * p.alpha;
+          if constexpr (BIAS) {
+            const int r = 8 * h8 + j;
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            x += bc.value(bc.pos_index(qi, key), bc.bucket(t_q1, bc.ts_at(key)));
+          }
           pv[j] = x * fast_sigmoid(x);
         }
         if (mode == 1) {          // plain causal: key <= query, both in range

@@ -242,6 +242,40 @@ HSTU_DEV MaskCtx make_mask_ctx(const HstuAttnParams& p, int b, int len) {
   return m;
 }
 
+// ---------------------------------------------------------------------------
+// research-path additive bias (research/modeling/sequential/hstu.py:87-144):
+//   bias[i,j] = pos_w[(N-1) + j - i] + ts_w[bucket(ts[i+1] - ts[j])],  ts[N] := ts[N-1]
+//   bucket(d) = clamp((int)(log(max(|d|,1)) / bucket_div), 0, num_buckets)     (fp32 log and divide)
+// ---------------------------------------------------------------------------
+struct BiasCtx {
+  const float* pos_w;
+  const float* ts_w;
+  const int64_t* ts_row;   // this user's timestamps (N entries) or nullptr
+  int n, nb;
+  float div;
+  HSTU_DEV int64_t ts_at(int pos) const { return ts_row ? ts_row[min(max(pos, 0), n - 1)] : 0; }
+  HSTU_DEV int pos_index(int qi, int key) const { return min(max(n - 1 + key - qi, 0), 2 * n - 2); }
+  HSTU_DEV int bucket(int64_t t_q1, int64_t t_k) const {
+    int64_t d = t_q1 - t_k;
+    d = d < 0 ? -d : d;
+    d = d < 1 ? 1 : d;
+    const int bk = (int)(logf((float)d) / div);
+    return min(max(bk, 0), nb);
+  }
+  HSTU_DEV float value(int pidx, int bkt) const { return pos_w[pidx] + (ts_w ? ts_w[bkt] : 0.f); }
+};
+
+HSTU_DEV BiasCtx make_bias_ctx(const HstuAttnParams& p, int b) {
+  BiasCtx c;
+  c.pos_w = p.pos_w;
+  c.ts_w = (p.ts_w && p.timestamps) ? p.ts_w : nullptr;
+  c.ts_row = c.ts_w ? p.timestamps + (int64_t)b * p.ts_row_stride : nullptr;
+  c.n = p.max_seq_len;
+  c.nb = p.num_buckets;
+  c.div = p.bucket_div;
+  return c;
+}
+
 // silu(s) = s * sigmoid(s), fp32, hardware exp2 / rcp (1 ulp each)
 HSTU_DEV float fast_sigmoid(float s) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * s));

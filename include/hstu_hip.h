@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 1
+#define HSTU_ABI_VERSION 2
 
 enum {
   HSTU_OK = 0,
@@ -80,6 +80,19 @@ typedef struct HstuAttnParams {
   int32_t dtype;          /* HSTU_DTYPE_* of q,k,v,out,dout,dq,dk,dv */
   int32_t offsets_dtype;  /* HSTU_INDEX_* of seq_offsets */
   int32_t targets_dtype;  /* HSTU_INDEX_* of num_targets */
+  /*
+   * Optional additive pre-activation bias of the research path
+   * (RelativeBucketedTimeAndPositionBasedBias, research/modeling/sequential/hstu.py:87-144):
+   *   S[i,j] += pos_w[(N-1) + j - i] + ts_w[clamp(floor(log(max(|ts[i+1]-ts[j]|,1)) / bucket_div), 0, num_buckets)]
+   * with ts[N] := ts[N-1], shared by all heads, N = max_seq_len.  pos_w == NULL disables it.
+   * ts_w / timestamps may be NULL (position-only bias, RelativePositionalBias :66-84).
+   */
+  const float* pos_w;          /* (2N-1) fp32 */
+  const float* ts_w;           /* (num_buckets+1) fp32 or NULL */
+  const int64_t* timestamps;   /* (B, ts_row_stride) int64 or NULL */
+  int64_t ts_row_stride;
+  int32_t num_buckets;         /* 128 in every shipped config */
+  float bucket_div;            /* 0.301 */
 } HstuAttnParams;
 
 /*
@@ -96,6 +109,8 @@ typedef struct HstuAttnBwdParams {
   int64_t dv_row_stride, dv_head_stride;
   void* workspace;        /* hstu_attn_bwd_workspace_bytes() bytes, or NULL if 0 */
   int64_t total_rows;     /* rows of q/k/v (= seq_offsets[B]), needed to size/zero the workspace */
+  float* dpos_w;          /* out (2N-1) fp32, required iff fwd.pos_w != NULL */
+  float* dts_w;           /* out (num_buckets+1) fp32, required iff fwd.ts_w != NULL */
 } HstuAttnBwdParams;
 
 /* library identity / errors */

@@ -44,7 +44,7 @@ def test_ctypes_signature_table_covers_header():
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.hstu_abi_version() == 1
+    assert lib.hstu_abi_version() == 2
     assert isinstance(lib.hstu_last_error(), bytes)
 
 
@@ -56,10 +56,11 @@ def test_struct_layout_matches_c():
 #include <stddef.h>
 #include "hstu_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(HstuAttnParams), offsetof(HstuAttnParams, batch),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(HstuAttnParams), offsetof(HstuAttnParams, batch),
          offsetof(HstuAttnParams, alpha), offsetof(HstuAttnParams, dtype), sizeof(HstuAttnBwdParams),
          offsetof(HstuAttnBwdParams, dout), offsetof(HstuAttnBwdParams, workspace),
-         offsetof(HstuAttnBwdParams, total_rows));
+         offsetof(HstuAttnBwdParams, total_rows), offsetof(HstuAttnParams, pos_w),
+         offsetof(HstuAttnParams, bucket_div), offsetof(HstuAttnBwdParams, dts_w));
   return 0;
 }
 """
@@ -71,7 +72,7 @@ int main(void) {
         got = [int(x) for x in subprocess.check_output([exe]).split()]
     P, BP = _lib.HstuAttnParams, _lib.HstuAttnBwdParams
     exp = [C.sizeof(P), P.batch.offset, P.alpha.offset, P.dtype.offset, C.sizeof(BP), BP.dout.offset,
-           BP.workspace.offset, BP.total_rows.offset]
+           BP.workspace.offset, BP.total_rows.offset, P.pos_w.offset, P.bucket_div.offset, BP.dts_w.offset]
     assert got == exp
 
 

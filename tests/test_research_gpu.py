@@ -1,0 +1,126 @@
+"""GPU tests of the research-path (relative position + bucketed time bias) attention and layer
+against the golden vectors of the reference's research/modeling/sequential/hstu.py and the oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_cases
+from oracle import hstu_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mods():
+    from generative_recommenders_amd.research.modeling.sequential import hstu
+
+    return hstu
+
+
+def _close(got, ref, rtol, atol_scale, what):
+    g = got.detach().float().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert g.shape == ref.shape, f"{what}: {g.shape} vs {ref.shape}"
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(g - ref)
+    bad = err > rtol * np.abs(ref) + atol_scale * scale
+    assert not bad.any(), f"{what}: {bad.sum()}/{bad.size} out of tolerance, max err {err.max():.3e}, scale {scale:.3e}"
+
+
+def test_golden_rel_bias_attention_fwd_bwd():
+    """fp32, vs the reference's _hstu_attention_maybe_from_cache + RelativeBucketedTimeAndPositionBasedBias."""
+    c = load_cases("research_attention.npz")[0]
+    m = _mods()
+    n, H, A, Ld = int(c["n"]), int(c["H"]), int(c["A"]), int(c["Ld"])
+    bias = m.RelativeBucketedTimeAndPositionBasedBias(max_seq_len=n, num_buckets=128).to(DEV)
+    with torch.no_grad():
+        bias._pos_w.copy_(torch.from_numpy(c["pos_w"]))
+        bias._ts_w.copy_(torch.from_numpy(c["ts_w"]))
+    q = torch.from_numpy(c["q"]).to(DEV).requires_grad_()
+    k = torch.from_numpy(c["k"]).to(DEV).requires_grad_()
+    v = torch.from_numpy(c["v"]).to(DEV).requires_grad_()
+    out = m.hstu_rel_bias_attention(H, A, Ld, q, k, v, torch.from_numpy(c["offsets"]).to(DEV),
+                                    torch.from_numpy(c["ts"]).to(DEV), n, bias)
+    _close(out, c["out"], 1e-3, 2e-6, "out")
+    out.backward(torch.from_numpy(c["g"]).to(DEV))
+    _close(q.grad, c["dq"], 1e-3, 1e-5, "dq")
+    _close(k.grad, c["dk"], 1e-3, 1e-5, "dk")
+    _close(v.grad, c["dv_"], 1e-3, 1e-5, "dv")
+    _close(bias._pos_w.grad, c["dpos_w"], 2e-3, 1e-4, "dpos_w")
+    _close(bias._ts_w.grad, c["dts_w"], 2e-3, 1e-4, "dts_w")
+
+
+@pytest.mark.parametrize("dtype,H,A,Ld,n,with_ts", [(torch.float32, 1, 50, 50, 60, True), (torch.bfloat16, 4, 64, 64, 211, True),
+                                                    (torch.float32, 2, 32, 32, 40, False), (torch.bfloat16, 2, 16, 32, 61, True)])
+def test_rel_bias_attention_vs_oracle(dtype, H, A, Ld, n, with_ts):
+    """ML-1M-like (1 head, d=50 -> padded), ML-20M-like (4 x 64, N = 211), position-only bias,
+    Amazon-Books-like short sequences (N = 61, long-tail lengths)."""
+    m = _mods()
+    rng = np.random.default_rng(n + H)
+    B = 6
+    lengths = rng.integers(1, n + 1, size=B)
+    lengths[0] = n
+    lengths[1] = max(1, n // 20)
+    off = O.complete_cumsum(lengths.astype(np.int64))
+    Lt = int(off[-1])
+    ts = np.sort(rng.integers(0, 10**8, size=(B, n)), axis=1).astype(np.int64)
+    mk = lambda d: torch.from_numpy(rng.standard_normal((Lt, H * d)) * 0.3).to(dtype)
+    q, k, v = mk(A), mk(A), mk(Ld)
+    g = torch.from_numpy(rng.standard_normal((Lt, H * Ld))).to(dtype)
+    bias = (m.RelativeBucketedTimeAndPositionBasedBias(n, 128) if with_ts else m.RelativePositionalBias(n)).to(DEV)
+    pos_w, ts_w, _, _ = bias.bias_params()
+    qd, kd, vd = (t.to(DEV).requires_grad_() for t in (q, k, v))
+    out = m.hstu_rel_bias_attention(H, A, Ld, qd, kd, vd, torch.from_numpy(off).to(DEV),
+                                    torch.from_numpy(ts).to(DEV) if with_ts else None, n, bias)
+    out.backward(g.to(DEV))
+    pw = pos_w.detach().double().cpu().numpy()
+    tw = None if ts_w is None else ts_w.detach().double().cpu().numpy()
+    q3, k3, v3 = (t.double().numpy().reshape(Lt, H, -1) for t in (q, k, v))
+    ref = O.rel_bias_attention_fwd(n, q3, k3, v3, off, ts if with_ts else None, pw, tw)
+    rq, rk, rv, rpos, rts = O.rel_bias_attention_bwd(n, g.double().numpy().reshape(Lt, H, Ld), q3, k3, v3, off,
+                                                     ts if with_ts else None, pw, tw)
+    tol = (1e-3, 1e-5) if dtype == torch.float32 else (3e-2, 6e-3)
+    _close(out, ref.reshape(Lt, -1), *tol, "out")
+    _close(qd.grad, rq.reshape(Lt, -1), *tol, "dq")
+    _close(kd.grad, rk.reshape(Lt, -1), *tol, "dk")
+    _close(vd.grad, rv.reshape(Lt, -1), *tol, "dv")
+    btol = (2e-3, 1e-4) if dtype == torch.float32 else (5e-2, 2e-2)
+    _close(pos_w.grad, rpos, *btol, "dpos_w")
+    if with_ts:
+        _close(ts_w.grad, rts, *btol, "dts_w")
+
+
+def test_research_layer_forward_backward_runs_and_matches_composition():
+    """SequentialTransductionUnitJagged on the fused kernels == the same math composed from the
+    oracle pieces (LN without affine -> uvqk -> SiLU on all -> bias attention -> u * LN(attn) -> Linear + x)."""
+    m = _mods()
+    torch.manual_seed(0)
+    D, H, A, Ld, n, B = 32, 2, 16, 16, 30, 4
+    layer = m.SequentialTransductionUnitJagged(D, Ld, A, 0.0, 0.0, H, "silu",
+                                               m.RelativeBucketedTimeAndPositionBasedBias(n, 128)).to(DEV)
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(1, n + 1, size=B)
+    off = O.complete_cumsum(lengths.astype(np.int64))
+    Lt = int(off[-1])
+    ts = np.sort(rng.integers(0, 10**7, size=(B, n)), axis=1).astype(np.int64)
+    x = torch.randn(Lt, D, device=DEV, requires_grad=True)
+    mask = torch.ones(n, n, device=DEV)
+    y, _ = layer(x, torch.from_numpy(off).to(DEV), torch.from_numpy(ts).to(DEV), mask)
+    y.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert layer._uvqk.grad is not None and layer._rel_attn_bias._ts_w.grad is not None
+    # reference composition in fp64
+    xn = x.detach().double().cpu().numpy()
+    nx = O.layer_norm_fwd(xn, np.ones(D), np.zeros(D), 1e-6)
+    mm = nx @ layer._uvqk.detach().double().cpu().numpy()
+    mm = mm / (1 + np.exp(-mm))
+    u, v, q, k = np.split(mm, [Ld * H, 2 * Ld * H, 2 * Ld * H + A * H], axis=1)
+    pos_w, ts_w, _, _ = layer._rel_attn_bias.bias_params()
+    attn = O.rel_bias_attention_fwd(n, q.reshape(Lt, H, A), k.reshape(Lt, H, A), v.reshape(Lt, H, Ld), off, ts,
+                                    pos_w.detach().double().cpu().numpy(), ts_w.detach().double().cpu().numpy())
+    a = O.layer_norm_fwd(attn.reshape(Lt, -1), np.ones(Ld * H), np.zeros(Ld * H), 1e-6)
+    ref = (u * a) @ layer._o.weight.detach().double().cpu().numpy().T + layer._o.bias.detach().double().cpu().numpy() + xn
+    _close(y, ref, 1e-3, 1e-4, "layer out")
+    sd_keys = sorted(layer.state_dict())
+    assert sd_keys == ["_o.bias", "_o.weight", "_rel_attn_bias._pos_w", "_rel_attn_bias._ts_w", "_uvqk"]
