@@ -1,0 +1,30 @@
+// Launcher of the folded backward schedule (hstu_attn_bwd_fold.cuh).
+#pragma once
+#include "capi_internal.h"
+#include "hstu_attn_bwd_fold.cuh"
+
+namespace hstu {
+
+template <typename T, int D>
+static int launch_bwd_fold_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
+  using F = FoldCfg<T, D, D>;
+  const HstuAttnParams& p = bp.fwd;
+  const int tmax = (p.max_seq_len + 31) / 32;
+  const int smem = F::smem_bytes();
+  auto kern = hstu_attn_bwd_fold_kernel<T, D, D>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(kBwdThreads), smem, st, bp, tmax);
+  return check_launch("hstu_attn_bwd(fold)");
+}
+
+template <typename T>
+static int launch_bwd_fold_dtype(const HstuAttnBwdParams& bp, hipStream_t st) {
+  if (bp.fwd.dqk == 128) return launch_bwd_fold_inst<T, 128>(bp, st);
+  if (bp.fwd.dqk == 64) return launch_bwd_fold_inst<T, 64>(bp, st);
+  return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd(fold): head dim %d not instantiated", bp.fwd.dqk);
+}
+
+}  // namespace hstu

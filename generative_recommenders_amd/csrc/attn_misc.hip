@@ -1,4 +1,6 @@
 // dtype-independent helpers of the attention ABI.
+#include <stdlib.h>
+
 #include "capi_internal.h"
 namespace hstu {
 int attn_bwd_tiles_bf16(int, int, int, int);
@@ -11,6 +13,18 @@ int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int ex
     case HSTU_DTYPE_F16: return attn_bwd_tiles_f16(dqk, dv, max_seq_len, extra_lds);
     default: return attn_bwd_tiles_f32(dqk, dv, max_seq_len, extra_lds);
   }
+}
+
+// The folded schedule needs: 16-bit I/O, no bias, no contextual rows, one key block of <= 7 tiles, and head
+// dims equal to an instantiated size (its LDS-DMA staging cannot zero-pad).  HSTU_BWD_FOLD=0 forces the
+// general kernel (A/B measurements).
+bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
+  const HstuAttnParams& p = bp.fwd;
+  static const bool enabled = [] { const char* e = getenv("HSTU_BWD_FOLD"); return !(e && e[0] == '0'); }();
+  if (!enabled) return false;
+  if (p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.contextual_seq_len > 0) return false;
+  if (p.dqk != p.dv || (p.dqk != 128 && p.dqk != 64)) return false;
+  return (p.max_seq_len + 31) / 32 <= 7;
 }
 
 size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& bp) {

@@ -21,6 +21,10 @@ int launch_attn_fwd_bias_f32(const HstuAttnParams& p, hipStream_t st);
 int launch_attn_bwd_bias_bf16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_bias_f16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_bias_f32(const HstuAttnBwdParams& p, hipStream_t st);
+// folded schedule of the backward for short sequences (hstu_attn_bwd_fold.cuh); 16-bit dtypes only
+int launch_attn_bwd_fold_bf16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_fold_f16(const HstuAttnBwdParams& p, hipStream_t st);
+bool attn_bwd_fold_applicable(const HstuAttnBwdParams& p);
 // sums the per-workgroup bias-gradient rows: partial (rows, width) -> dpos_w (npos), dts_w (width - npos)
 int launch_bias_grad_reduce(const float* partial, int rows, int width, int npos, float* dpos_w, float* dts_w,
                             hipStream_t st);

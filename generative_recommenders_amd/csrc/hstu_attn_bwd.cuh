@@ -261,8 +261,6 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int key_id = mc.id_of(key);
   int64_t t_k = 0;
   if constexpr (BIAS) t_k = bc.ts_at(key);
-  // last (smallest) query tile this owner takes part in: its diagonal, or tile 0 with contextual rows
-  const int my_last_it = (mc.ctx > 0) ? it_lo : max(it_lo, kt0 + wave);
 
   for (int it = it_hi - 1; it >= it_lo; --it) {
     const int i0 = it << 5;

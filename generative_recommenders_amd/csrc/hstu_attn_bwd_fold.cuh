@@ -1,0 +1,511 @@
+// HSTU attention backward, "folded" schedule for short sequences (the metric shape): one workgroup
+// of 8 waves per (user, head), the whole sequence (<= 7 tiles of 32 rows) in ONE key block.
+//
+// Same math, fragments and LDS tiles as hstu_attn_bwd.cuh (owner wave of a key tile keeps dK/dV in
+// registers, dS' goes through LDS, dQ is a GEMM over the key tiles).  What changes is the schedule.
+// The causal triangle gives key tile w one (query tile, key tile) pair per query tile >= w, so in the
+// plain schedule (one query tile per step) the owner of key tile 0 works in every step while the
+// others idle: 7 steps for 28 pairs on 8 waves.  Here every step takes TWO query tiles, one from
+// each end of the sequence:
+//     step k:   side A = query tile a = nt-1-k  (needs key tiles 0..a   -> a+1 owner waves 0..a)
+//               side B = query tile b = k       (needs key tiles 0..b   -> b+1 owner waves 7-b..7)
+// a + b = nt-1 <= 6, so the two sides always fit the 8 waves with all of them busy, and the loop
+// has ceil(nt/2) steps instead of nt.  A wave first owns key tile w on side A (until the diagonal
+// step a == w, after which that tile's dK/dV are final unless side B also reaches it: it is stored
+// on the spot), then may own key tile 7-w on side B.  The side-B partial sums of key tiles
+// 0..floor(nt/2)-1 are handed to their side-A owners through LDS after the loop.
+// dQ of both query tiles of a step is complete within the step (all their key tiles are visited in
+// it): a 16x16x32-MFMA GEMM in which every wave owns 16 feature columns of both tiles (balanced for any
+// split between the sides), straight to HBM in the I/O dtype.
+//
+// LDS (16-bit I/O, DQK = DV = 128): 7 K/V tile pairs (112 KiB) + 2 Q/dO stages (32 KiB) + 8 dS'
+// tiles (16 KiB, unpadded, 8-byte chunks XOR-swizzled) = exactly 160 KiB.  All global -> LDS traffic
+// is LDS-DMA; the Q/dO tiles of step k+1 are fetched while the dQ GEMM of step k runs.
+// Requires: no contextual rows (pair (i, w) active only for w <= i), head dims equal to the
+// instantiated ones (LDS-DMA cannot zero-fill), 16-bit I/O, max_seq_len <= 224.
+#pragma once
+#include "hstu_attn_bwd.cuh"
+
+#ifndef FOLD_DQ_DEPTH
+#define FOLD_DQ_DEPTH 1   // slots of transposed reads in flight ahead of the MFMAs (2 spills registers)
+#endif
+
+namespace hstu {
+
+template <typename T, int DQK, int DV>
+struct FoldCfg {
+  using B = BwdCfg<T, DQK, DV>;
+  static constexpr int DSB = 32 * 64;                    // [32 keys][32 q] 16-bit tile, 64-byte rows
+  static constexpr int kMaxTiles = kBwdWaves - 1;
+  // all kMaxTiles K/V slots are always allocated (the dQ GEMM reads every slot, used or not)
+  static constexpr int smem_bytes() { return (kMaxTiles + 2) * B::PAIR + kBwdWaves * DSB; }
+};
+
+// LDS-DMA of one [32][D] tile (as tile_dma in hstu_attn_fwd.cuh), issued through inline asm.  Why asm: for the
+// builtin, hipcc's waitcnt pass assumes that ANY later LDS read may alias the tile in flight and puts an
+// s_waitcnt vmcnt(0) in front of it -- here that is the first read of the dQ GEMM, which only touches K tiles and
+// dS' buffers, so the whole HBM latency of the next step's Q/dO tiles (the very thing the DMA is issued early to
+// hide) would be waited out on the spot.  The asm form is invisible to that pass; the kernel orders its consumers
+// by hand: s_waitcnt vmcnt(0) + barrier at the top of every step, before the first read of a DMA'd tile.
+// (The compiler's own vmcnt bookkeeping stays safe: unknown extra operations in flight only make a counted wait
+// stricter, memory operations complete in order.)  M0 carries the LDS base of the 1 KiB chunk.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+HSTU_DEV void dma16_asm(const char* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+template <typename T, int D>
+HSTU_DEV void fold_tile_dma(char* tile, const char* base, int64_t row_stride_bytes, int row0, int len, int wave, int lane) {
+  constexpr int UPR = D * Elem<T>::kBytes / 16;
+  constexpr int NCH = 32 * UPR / 64;   // 1 KiB chunks per tile
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile);
+  for (int c = wave; c < NCH; c += kBwdWaves) {
+    const int pidx = c * 64 + lane;
+    const int row = pidx / UPR, slot = pidx % UPR;
+    const int unit = slot ^ swz<UPR>(row);
+    const int grow = min(row0 + row, len - 1);
+    dma16_asm(base + (int64_t)grow * row_stride_bytes + unit * 16, lds0 + c * 1024);
+  }
+}
+
+// byte offset of the 8-byte chunk `chunk` (4 query columns) of key row `row` in a dS' tile
+// The XOR term (row >> 1) & 7 makes all three users conflict-free: the owners' ds_write_b64 (16 rows, one chunk
+// column: 16 distinct 8-byte positions of the 128-byte store window), and the 16x16x32 transposed reads of the
+// dQ GEMM (a 32-lane group reads rows 8g..8g+3 of g = 0,1: four 64-byte quarters x two different 32-byte halves).
+HSTU_DEV int fold_ds_off(int row, int chunk) { return (row << 6) + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+// One (query tile i0, key tile k0) pair on the owner wave: S, dP, P', dS', dV += , dK +=, publish dS'.
+template <typename T, int DQK, int DV>
+HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* __restrict__ Kw, const char* __restrict__ Vw,
+                        const char* __restrict__ Qs, const char* __restrict__ dOs, char* __restrict__ myds, int i0, int k0, f32x16 (&dk_acc)[DQK / 32],
+                        f32x16 (&dv_acc)[DV / 32], int lane HSTU_TRACE_ARG) {
+  using C = BwdCfg<T, DQK, DV>;
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  const int n32 = lane & 31, hf = lane >> 5;
+  const int len = mc.len;
+  const int key = k0 + n32;
+  const bool key_ok = key < len;
+  f32x16 s, dp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+  for (int kg = 0; kg < C::KGQ; ++kg) {
+    const int e0 = hf * (DQK / 2) + kg * 8;
+    Frag a = lds_row_frag<T, C::UPR_K>(Qs, n32, e0);
+    Frag bb = lds_row_frag<T, C::UPR_K>(Kw, n32, e0);
+    s = E::mma(a, bb, s);
+  }
+#pragma unroll
+  for (int kg = 0; kg < C::KGV; ++kg) {
+    const int e0 = hf * (DV / 2) + kg * 8;
+    Frag a = lds_row_frag<T, C::UPR_V>(dOs, n32, e0);
+    Frag bb = lds_row_frag<T, C::UPR_V>(Vw, n32, e0);
+    dp = E::mma(a, bb, dp);
+  }
+  HSTU_MARK(11);
+  // C layout: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf.  Query rows >= len
+  // hold a clamped copy of a real row (LDS-DMA cannot zero-fill), so only tiles entirely inside the
+  // sequence may skip the per-element mask.
+  Frag pb[2], dsb[2];
+  int mode;   // wave-uniform: 0 = no mask needed, 1 = plain causal, 2 = general mask algebra
+  if (mc.simple) mode = (k0 < i0 && i0 + 32 <= len) ? 0 : 1;    // strictly below the diagonal and all rows real
+  else mode = (i0 + 32 <= len && mc.pair_fully_valid(i0, 32, k0, 32)) ? 0 : 2;
+  const int key_id = mc.id_of(key);
+#pragma unroll
+  for (int h8 = 0; h8 < 2; ++h8) {
+    float pv[8], dsv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 8 * h8 + j;
+      const float x = s[r] * p.alpha;
+      const float sg = fast_sigmoid(x);
+      pv[j] = x * sg;
+      dsv[j] = dp[r] * sg * (1.f + x * (1.f - sg));
+    }
+    if (mode == 1) {
+      // plain causal: keep (key <= qi) & (qi < len) (then key < len too).  Integer arithmetic only: compares would
+      // go through SGPR pairs and the scalar unit, a VALU -> SALU -> VALU round trip per element.
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * h8 + j;
+        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const int q_eff = qi | ((len - 1 - qi) >> 31);          // qi, or -1 when qi >= len
+        const int keep = (key - 1 - q_eff) >> 31;                // all ones iff key <= q_eff
+        pv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, pv[j]) & keep);
+        dsv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, dsv[j]) & keep);
+      }
+    } else if (mode == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * h8 + j;
+        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const bool ok = key_ok & (qi < len) & mc.valid_ids(qi, key, mc.id_of(qi), key_id);
+        pv[j] = ok ? pv[j] : 0.f;
+        dsv[j] = ok ? dsv[j] : 0.f;
+      }
+    }
+    pb[h8] = E::pack8(pv);
+    dsb[h8] = E::pack8(dsv);
+  }
+  HSTU_MARK(12);
+  // dV_w^T[dv][key] += dO_i^T[dv][q] P'[q][key]
+#pragma unroll
+  for (int d = 0; d < C::DBV; ++d)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag a = lds_col_frag<T, C::UPR_V>(dOs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+      dv_acc[d] = E::mma(a, pb[ks], dv_acc[d]);
+    }
+  // dK_w^T[d][key] += Q_i^T[d][q] dS'[q][key]
+#pragma unroll
+  for (int d = 0; d < C::DBQ; ++d)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag a = lds_col_frag<T, C::UPR_K>(Qs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+      dk_acc[d] = E::mma(a, dsb[ks], dk_acc[d]);
+    }
+  // publish dS' as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3) = chunk hf + 2 rq
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const u32x4 w = __builtin_bit_cast(u32x4, dsb[rq >> 1].v);
+    u32x2 v2 = {w[2 * (rq & 1)], w[2 * (rq & 1) + 1]};
+    *LDS_PTR(u32x2, myds + fold_ds_off(n32, hf + 2 * rq)) = v2;
+  }
+}
+
+// Finished dk / dv tiles leave the workgroup in two moves.  (1) PARK: the owner wave writes its transposed
+// accumulators (column n32 = key, registers = features), scaled and rounded to the I/O dtype, as a swizzled
+// row-major [32 keys][D] tile into LDS -- in place of the K (or V) tile of the same keys, which is dead by then.
+// (2) COPY OUT: all 8 waves move parked tiles to global memory, one 16-byte unit per thread, 16 consecutive lanes
+// per 256-byte row: one dwordx4 store per wave per tile.  Storing the accumulators directly takes D/4 dwordx2
+// stores per lane, each touching 64 different rows, all issued by ONE wave: that is store-issue bound (some 4k
+// cycles per tile pair on the wave the others are waiting for).
+template <typename T, int D>
+HSTU_DEV void fold_park_tile(const f32x16 (&acc)[D / 32], float scale, char* __restrict__ tile, int lane) {
+  constexpr int UPR = D * Elem<T>::kBytes / 16;
+  const int n32 = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int d = 0; d < D / 32; ++d)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      u32x2 v = {Elem<T>::pk2(acc[d][4 * rq] * scale, acc[d][4 * rq + 1] * scale),
+                 Elem<T>::pk2(acc[d][4 * rq + 2] * scale, acc[d][4 * rq + 3] * scale)};
+      *LDS_PTR(u32x2, tile + tile_off<UPR>(n32, 4 * d + rq) + 8 * hf) = v;
+    }
+}
+template <typename T, int D>
+HSTU_DEV void fold_copy_out(const char* __restrict__ tile, char* gtile, int64_t row_stride_bytes, int rows_valid, int tid) {
+  constexpr int UPR = D * Elem<T>::kBytes / 16;
+  for (int u = tid; u < 32 * UPR; u += kBwdThreads) {
+    const int row = u / UPR, unit = u % UPR;
+    const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, unit));
+    if (row < rows_valid) gstore16(gtile + row * row_stride_bytes + unit * 16, v);
+  }
+}
+
+// lane-linear fp32 dump / reload-and-add of an accumulator set (hand-over of a partial sum between two waves)
+template <int NB>
+HSTU_DEV void fold_dump(const f32x16 (&acc)[NB], char* __restrict__ region, int lane) {
+#pragma unroll
+  for (int d = 0; d < NB; ++d)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 v4 = {acc[d][4 * c], acc[d][4 * c + 1], acc[d][4 * c + 2], acc[d][4 * c + 3]};
+      *LDS_PTR(f32x4, region + ((d * 4 + c) * 64 + lane) * 16) = v4;
+    }
+}
+template <int NB>
+HSTU_DEV void fold_add(f32x16 (&acc)[NB], const char* __restrict__ region, int lane) {
+#pragma unroll
+  for (int d = 0; d < NB; ++d)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 v4 = *LDS_PTR(const f32x4, region + ((d * 4 + c) * 64 + lane) * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[d][4 * c + e] += v4[e];
+    }
+}
+
+// 8-element fragment of a 16x16x32 MFMA for a contraction ACROSS the rows of a row-major LDS tile:
+// lane (i16 = lane & 15, g = lane >> 4) gets rows 8g..8g+7 of one 16-bit column; `off_lo` / `off_hi` are this
+// lane's byte offsets for rows 8g + (i16 >> 2) and 8g + 4 + (i16 >> 2) (transpose reads, see lds_col_frag).
+template <typename T>
+HSTU_DEV typename Elem<T>::Frag tr_frag16(const char* base, int off_lo, int off_hi) {
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + off_lo));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + off_hi));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 ab = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  typename Elem<T>::Frag f;
+  f.v = __builtin_bit_cast(typename Elem<T>::vec8, ab);
+  return f;
+}
+
+// dQ of the two query tiles of a step.  dQ^T[d][q] = sum over key tiles of K_t^T[d][key] dS'_t^T[key][q] with the
+// 16x16x32 MFMA (one key tile = one contraction): wave w < DQK/16 owns the 16 feature columns [16 w, +16) of BOTH
+// query tiles (2 x 2 accumulators of 16 q rows), so every wave runs (a+1) + (b+1) = nt + 1 tile contractions per step
+// whatever the split between the sides.  The dS' tile of key tile t was published by its owner wave: wave t on
+// side A, wave 7 - t on side B.  Fragments of the next contraction are in flight under the MFMAs of this one.
+template <typename T, int DQK, int DV>
+HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv,
+                            const char* __restrict__ dsbuf, int a, int bq, bool b_on, int wave, int64_t off0, int hd,
+                            float ds_scale, int lane HSTU_TRACE_ARG) {
+  using C = BwdCfg<T, DQK, DV>;
+  using F = FoldCfg<T, DQK, DV>;
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  if (wave >= DQK / 16) return;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int row_lo = 8 * g + (i16 >> 2), row_hi = row_lo + 4;
+  const int colK = 16 * wave + 4 * (i16 & 3);
+  const int k_lo = tile_off<C::UPR_K>(row_lo, colK >> 3) + ((colK & 7) << 1);
+  const int k_hi = tile_off<C::UPR_K>(row_hi, colK >> 3) + ((colK & 7) << 1);
+  const int d0_lo = fold_ds_off(row_lo, i16 & 3), d0_hi = fold_ds_off(row_hi, i16 & 3);             // q rows 0..15
+  const int d1_lo = fold_ds_off(row_lo, 4 + (i16 & 3)), d1_hi = fold_ds_off(row_hi, 4 + (i16 & 3));   // q rows 16..31
+  // The key-tile loops are STATIC (7 slots for side A, 4 for side B -- b <= 3 -- fully unrolled, no branches): a
+  // slot without work reads whatever its LDS slot holds and gets its K^T fragment zeroed (the dS' buffers only ever hold finite
+  // values: they are cleared at kernel start).  Straight-line code is what lets hipcc keep the LDS reads of the
+  // next slots in flight under the MFMAs of this one (counted lgkmcnt waits); a runtime work list makes it drain
+  // lgkmcnt to 0 at every block boundary and serialises (LDS latency + MFMA) per key tile.
+  // (Scalar work is not free either: without an attention window every tile on or below the diagonal is active,
+  // so the per-tile predicate -- some 50 SALU instructions -- is only evaluated when there is a window.)
+  unsigned on_a = (1u << (a + 1)) - 1u, on_b = b_on ? (1u << (bq + 1)) - 1u : 0u;
+  if (mc.win != 0) {
+    for (int t = 0; t <= a; ++t)
+      if (!mc.pair_may_be_active(32 * a, 32, 32 * t, 32)) on_a &= ~(1u << t);
+    if (b_on)
+      for (int t = 0; t <= bq; ++t)
+        if (!mc.pair_may_be_active(32 * bq, 32, 32 * t, 32)) on_b &= ~(1u << t);
+  }
+  HSTU_MARK(19);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) acc[sd][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+#pragma unroll
+    for (int t = 0; t < (sd ? 4 : F::kMaxTiles); ++t) {
+      const bool on = ((sd ? on_b : on_a) >> t) & 1u;
+      const char* Kt = kv + t * C::PAIR;                          // all 7 slots are always allocated
+      const char* ds = dsbuf + (sd ? (kBwdWaves - 1 - t) : t) * F::DSB;
+      Frag fk = tr_frag16<T>(Kt, k_lo, k_hi);
+      const Frag f0 = tr_frag16<T>(ds, d0_lo, d0_hi), f1 = tr_frag16<T>(ds, d1_lo, d1_hi);
+      fk.v = __builtin_bit_cast(typename E::vec8, on ? __builtin_bit_cast(u32x4, fk.v) : zero4);
+      acc[sd][0] = E::mma16(fk, f0, acc[sd][0]);
+      acc[sd][1] = E::mma16(fk, f1, acc[sd][1]);
+    }
+  }
+  // requested instruction order (hipcc would otherwise, short of registers, serialise read -> wait -> MFMA per
+  // slot): the 6 transposed reads of slot s+DEPTH are issued ahead of the MFMA pair of slot s
+  if (FOLD_DQ_DEPTH > 0) {
+    constexpr int NSLOT = F::kMaxTiles + 4;
+    __builtin_amdgcn_sched_group_barrier(0x100, 6 * FOLD_DQ_DEPTH, 0);
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      if (FOLD_DQ_DEPTH == 1 && sl + 1 < NSLOT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // zeroing of an idle slot's K^T fragment
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (FOLD_DQ_DEPTH == 2 && sl + 2 < NSLOT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    }
+  }
+  HSTU_MARK(16);
+  // C layout: column i16 = query row, register r = feature 16 wave + 4 g + r
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+    if (sd == 1 && !b_on) break;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = 32 * (sd ? bq : a) + 16 * qb + i16;
+      if (qrow < mc.len) {
+        char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
+        store4<T>(dqrow, 16 * wave + 4 * g, acc[sd][qb][0] * ds_scale, acc[sd][qb][1] * ds_scale, acc[sd][qb][2] * ds_scale,
+                  acc[sd][qb][3] * ds_scale);
+      }
+    }
+  }
+}
+
+template <typename T, int DQK, int DV>
+__global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_fold_kernel(const HstuAttnBwdParams bp, int tmax) {
+  using C = BwdCfg<T, DQK, DV>;
+  using F = FoldCfg<T, DQK, DV>;
+  static_assert(C::EB == 2, "the folded backward is built for 16-bit I/O");
+  static_assert(DQK / 16 <= kBwdWaves, "dQ GEMM: one 16-column block per wave");
+  static_assert(DQK == DV, "hand-over regions assume equal K and V tile sizes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const HstuAttnParams& p = bp.fwd;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int uh = blockIdx.x;
+  const int b = uh / p.heads, hd = uh % p.heads;
+  const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
+  const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
+  if (len <= 0) return;
+  const MaskCtx mc = make_mask_ctx(p, b, len);
+  HSTU_TRACE_DECL(bp.workspace, bp.workspace != nullptr && blockIdx.x == 4096);
+  HSTU_MARK(1);
+
+  const int nt = (len + 31) >> 5;        // tiles of this user (<= tmax <= 7)
+  const int ns = (nt + 1) >> 1;          // steps
+  char* const stageA = smem + F::kMaxTiles * C::PAIR;
+  char* const stageB = stageA + C::PAIR;
+  char* const dsbuf = stageB + C::PAIR;
+
+  const char* qbase = (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
+  const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
+  const char* vbase = (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * C::EB;
+  const char* dobase = (const char*)bp.dout + (off0 * bp.do_row_stride + (int64_t)hd * bp.do_head_stride) * C::EB;
+  char* const dk_head = (char*)bp.dk + (off0 * bp.dk_row_stride + (int64_t)hd * bp.dk_head_stride) * C::EB;
+  char* const dv_head = (char*)bp.dv + (off0 * bp.dv_row_stride + (int64_t)hd * bp.dv_head_stride) * C::EB;
+  const int64_t dk_rs = bp.dk_row_stride * C::EB, dv_rs = bp.dv_row_stride * C::EB;
+  const int64_t q_rs = p.q_row_stride * C::EB, k_rs = p.k_row_stride * C::EB, v_rs = p.v_row_stride * C::EB,
+                do_rs = bp.do_row_stride * C::EB;
+
+  auto stage_dma = [&](int qa, int qb, bool b_on) {
+    fold_tile_dma<T, DQK>(stageA, qbase, q_rs, 32 * qa, len, wave, lane);
+    fold_tile_dma<T, DV>(stageA + C::KT, dobase, do_rs, 32 * qa, len, wave, lane);
+    if (b_on) {
+      fold_tile_dma<T, DQK>(stageB, qbase, q_rs, 32 * qb, len, wave, lane);
+      fold_tile_dma<T, DV>(stageB + C::KT, dobase, do_rs, 32 * qb, len, wave, lane);
+    }
+  };
+
+  // ---- prologue: the whole K/V block and the first two query tiles, all by LDS-DMA
+  for (int t = 0; t < nt; ++t) {
+    char* dst = smem + t * C::PAIR;
+    fold_tile_dma<T, DQK>(dst, kbase, k_rs, 32 * t, len, wave, lane);
+    fold_tile_dma<T, DV>(dst + C::KT, vbase, v_rs, 32 * t, len, wave, lane);
+  }
+  stage_dma(nt - 1, 0, 0 < nt - 1);
+  for (int i = tid; i < kBwdWaves * F::DSB / 16; i += kBwdThreads) *LDS_PTR(u32x4, dsbuf + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+  HSTU_MARK(2);
+
+  f32x16 dk_acc[C::DBQ], dv_acc[C::DBV];
+#pragma unroll
+  for (int d = 0; d < C::DBQ; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk_acc[d][r] = 0.f;
+#pragma unroll
+  for (int d = 0; d < C::DBV; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv_acc[d][r] = 0.f;
+  const float ds_scale = p.scale * p.alpha;
+
+  for (int k = 0; k < ns; ++k) {
+    const int a = nt - 1 - k, bq = k;
+    const bool b_on = bq < a;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // Q/dO tiles of this step (and, first time, K/V) landed; dS' of the last step consumed
+    HSTU_MARK(10);
+    if (k > 0 && wave == a + 1) {
+      // owner of the previous step's diagonal tile: its K tile is dead now (every dQ GEMM of that step is done):
+      // park dK in its place; dV was parked before the barrier, so the accumulators are free for a side-B tile
+      int lane3 = lane;
+      asm volatile("" : "+v"(lane3));
+      fold_park_tile<T, DQK>(dk_acc, ds_scale, smem + wave * C::PAIR, lane3);
+#pragma unroll
+      for (int d = 0; d < C::DBQ; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk_acc[d][r] = 0.f;
+    }
+    // ---- phase 1: this wave's pair of the step
+    int kt = -1, qt = 0;
+    const char* st = stageA;
+    if (wave <= a) { kt = wave; qt = a; }
+    else if (b_on && kBwdWaves - 1 - wave <= bq) { kt = kBwdWaves - 1 - wave; qt = bq; st = stageB; }
+    if (kt >= 0 && (mc.win == 0 || mc.pair_may_be_active(32 * qt, 32, 32 * kt, 32))) {
+      const char* Kw = smem + kt * C::PAIR;
+      // (the lane id is laundered per phase: LDS offsets derived from it are then recomputed where they are used --
+      // a few dozen VALU instructions -- instead of being hoisted out of the step loop, where some 60 of them,
+      // alive across both phases next to the 128 accumulator registers, push the kernel into spilling)
+      int lane1 = lane;
+      asm volatile("" : "+v"(lane1));
+      fold_pair<T, DQK, DV>(p, mc, Kw, Kw + C::KT, st, st + C::KT, dsbuf + wave * F::DSB, 32 * qt, 32 * kt, dk_acc,
+                            dv_acc, lane1 HSTU_TRACE_PASS);
+    }
+    HSTU_MARK(13);
+    HSTU_MARK(14);
+    __syncthreads();   // dS' of this step published; stage reads done
+    HSTU_MARK(15);
+#ifndef HSTU_FOLD_DMA_LATE
+    if (k + 1 < ns) stage_dma(a - 1, bq + 1, bq + 1 < a - 1);
+#endif
+    if (k > 0) {   // dk / dv of the previous step's diagonal key tile (parked in K/V slot a + 1): out, by all waves
+      const int kt1 = a + 1;
+      fold_copy_out<T, DQK>(smem + kt1 * C::PAIR, dk_head + (int64_t)(32 * kt1) * dk_rs, dk_rs, len - 32 * kt1, tid);
+      fold_copy_out<T, DV>(smem + kt1 * C::PAIR + C::KT, dv_head + (int64_t)(32 * kt1) * dv_rs, dv_rs, len - 32 * kt1, tid);
+    }
+    HSTU_MARK(18);
+    // ---- phase 2: dQ of the two query tiles, 16 feature columns per wave
+    int lane2 = lane;
+    asm volatile("" : "+v"(lane2));
+    fold_dq_phase<T, DQK, DV>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
+    HSTU_MARK(17);
+    if (kt == wave && wave == a) {
+      // diagonal step of side A: no later query tile reaches key tile `wave`, its dK/dV are final (a >= nt/2 in
+      // every step, so it is never one of the side-B tiles 0..nt/2-1).  dV is parked right away: V tiles are only
+      // read by their owner's pairs and this owner has just done its last one.  The K tile may still be read by
+      // other waves' dQ GEMM: dK follows after the next barrier.
+      int lane3 = lane;
+      asm volatile("" : "+v"(lane3));
+      fold_park_tile<T, DV>(dv_acc, p.scale, smem + wave * C::PAIR + C::KT, lane3);
+#pragma unroll
+      for (int d = 0; d < C::DBV; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv_acc[d][r] = 0.f;
+    }
+    HSTU_MARK(23);
+#ifdef HSTU_FOLD_DMA_LATE
+    if (k + 1 < ns) stage_dma(a - 1, bq + 1, bq + 1 < a - 1);
+#endif
+  }
+  HSTU_MARK(20);
+  // ---- tail.  Key tiles 0..nb-1 have two partial sums: side A (wave t) and side B (wave 7 - t).  Each of the two
+  // waves finishes HALF of the tile: the side-A owner hands its dV partial over and finishes dK, the side-B owner
+  // hands its dK partial over and finishes dV.  Hand-over regions (fp32, lane-linear, one K/V slot's size each):
+  // side A -> K/V slot t, side B -> stage A / stage B / dS' buffers for t = 0 / 1 / 2 (all dead by now).  The
+  // finished halves are parked in the region the wave has just read, then everything parked goes out together.
+  const int nb = nt >> 1;
+  const int a_last = nt - ns;                      // diagonal tile of the last step: dV parked, dK still in registers
+  const int bt = kBwdWaves - 1 - wave;
+  const bool a_fin = wave < nb, b_fin = bt < nb;
+  const int tb = a_fin ? wave : bt;
+  char* const reg_a = smem + tb * C::PAIR;
+  char* const reg_b = tb == 0 ? stageA : (tb == 1 ? stageB : dsbuf);
+  __syncthreads();     // K/V tiles, stages and dS' buffers are dead from here on
+  int lane4 = lane;
+  asm volatile("" : "+v"(lane4));
+  if (wave == a_last) fold_park_tile<T, DQK>(dk_acc, ds_scale, smem + wave * C::PAIR, lane4);
+  if (a_fin) fold_dump<C::DBV>(dv_acc, reg_a, lane4);
+  if (b_fin) fold_dump<C::DBQ>(dk_acc, reg_b, lane4);
+  __syncthreads();
+  HSTU_MARK(22);
+  if (a_fin) {
+    fold_add<C::DBQ>(dk_acc, reg_b, lane4);
+    fold_park_tile<T, DQK>(dk_acc, ds_scale, reg_b, lane4);
+  }
+  if (b_fin) {
+    fold_add<C::DBV>(dv_acc, reg_a, lane4);
+    fold_park_tile<T, DV>(dv_acc, p.scale, reg_a + C::KT, lane4);
+  }
+  __syncthreads();
+  HSTU_MARK(24);
+  fold_copy_out<T, DQK>(smem + a_last * C::PAIR, dk_head + (int64_t)(32 * a_last) * dk_rs, dk_rs, len - 32 * a_last, tid);
+  fold_copy_out<T, DV>(smem + a_last * C::PAIR + C::KT, dv_head + (int64_t)(32 * a_last) * dv_rs, dv_rs, len - 32 * a_last, tid);
+  for (int t = 0; t < nb; ++t) {
+    const char* rb = t == 0 ? stageA : (t == 1 ? stageB : dsbuf);
+    fold_copy_out<T, DQK>(rb, dk_head + (int64_t)(32 * t) * dk_rs, dk_rs, len - 32 * t, tid);
+    fold_copy_out<T, DV>(smem + t * C::PAIR + C::KT, dv_head + (int64_t)(32 * t) * dv_rs, dv_rs, len - 32 * t, tid);
+  }
+  HSTU_MARK(21);
+}
+
+}  // namespace hstu

@@ -101,9 +101,7 @@ HSTU_DEV void tile_dma(char* tile, const char* base, int64_t row_stride_bytes, i
   for (int c = wave; c < NCH; c += nwaves) {
     const int pidx = c * 64 + lane;
     const int row = pidx / UPR, slot = pidx % UPR;
-    int unit;
-    if constexpr (UPR >= 16) unit = slot ^ (row & 15);
-    else unit = slot ^ ((row / (16 / UPR)) & (UPR - 1));
+    const int unit = slot ^ swz<UPR>(row);
     const int grow = min(row0 + row, len - 1);
     const int gunit = (unit * EPU < real_d) ? unit : 0;
     const char* g = base + (int64_t)grow * row_stride_bytes + gunit * 16;

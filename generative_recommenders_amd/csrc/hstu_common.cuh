@@ -47,6 +47,10 @@ template <> struct Elem<bf16_t> {
   static HSTU_DEV f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
   }
+  // 16x16x32: A[m = lane&15][k = 8 (lane>>4) + j], B[k][n = lane&15], C[m = 4 (lane>>4) + r][n = lane&15]
+  static HSTU_DEV f32x4 mma16(const Frag& a, const Frag& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+  }
   static HSTU_DEV uint32_t pk2(float a, float b) {   // one v_cvt_pk_bf16_f32
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef bf16_t h2 __attribute__((ext_vector_type(2)));
@@ -68,6 +72,9 @@ template <> struct Elem<f16_t> {
   struct Frag { vec8 v; };
   static HSTU_DEV f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, c, 0, 0, 0);
+  }
+  static HSTU_DEV f32x4 mma16(const Frag& a, const Frag& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.v, c, 0, 0, 0);
   }
   static HSTU_DEV uint32_t pk2(float a, float b) {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -107,17 +114,25 @@ template <typename T> HSTU_DEV float to_f32(T x) { return (float)x; }
 // ---------------------------------------------------------------------------
 // LDS tile layout
 // ---------------------------------------------------------------------------
-// Units are 16 bytes.  UPR = units per row (power of two).  Returns the byte
-// offset of unit `u` of row `r` inside a tile of 32 (or more) rows.
-template <int UPR> HSTU_DEV int tile_off(int r, int u) {
+// Units are 16 bytes.  UPR = units per row (power of two).  tile_off returns the byte offset of
+// unit `u` of row `r` inside a tile of 32 (or more) rows: unit u sits in slot u ^ swz(r) of its row.
+// swz is chosen for BOTH access patterns of the kernels (LDS = 64 banks x 4 B = a 256-byte window):
+//  * ds_read_b128 of one unit column from 16 different rows (16-lane groups whose rows have 16
+//    distinct values of r & 15): swz must be a bijection of r & 15 onto the slots sharing a window;
+//  * ds_read_b64_tr_b16 (32-lane groups = 4 consecutive rows 4m..4m+3 x one 64-byte, 4-unit-aligned
+//    column block): the four rows must land in four DIFFERENT 64-byte quarters of the window, i.e.
+//    r & 3 must drive the quarter.  (A plain u ^ (r & 15) puts all four rows in the same quarter:
+//    a 4-way conflict on every transposed read.)
+template <int UPR> HSTU_DEV int swz(int r) {
   static_assert((UPR & (UPR - 1)) == 0, "UPR must be a power of two");
-  if constexpr (UPR >= 16) {
-    return (r * UPR + (u ^ (r & 15))) << 4;
-  } else {
-    constexpr int RPB = 16 / UPR;  // rows per 256-byte bank row
-    return (r * UPR + (u ^ ((r / RPB) & (UPR - 1)))) << 4;
-  }
+#ifdef HSTU_SWZ_OLD
+  if constexpr (UPR >= 16) return r & 15; else return (r / (16 / UPR)) & (UPR - 1);
+#endif
+  if constexpr (UPR >= 16) return ((r & 3) << 2) | ((r >> 2) & 3);             // 256-byte rows (or longer)
+  else if constexpr (UPR == 8) return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);  // 2 rows per window: quarter = (r&1, r>>1&1)
+  else return (r / (16 / UPR)) & (UPR - 1);                                     // >= 4 rows per window: quarters differ already
 }
+template <int UPR> HSTU_DEV int tile_off(int r, int u) { return (r * UPR + (u ^ swz<UPR>(r))) << 4; }
 
 // Fragment of a row-major tile for a contraction along the row:
 // elements [e0, e0+8) of row `row`.  16-bit: one unit; fp32: two units.
@@ -285,17 +300,22 @@ HSTU_DEV float fast_sigmoid(float s) {
 // lane 0 of every wave of ONE workgroup appends s_memtime stamps to a global buffer.
 #ifdef HSTU_TRACE
 static __device__ unsigned long long* g_hstu_trace_fwd = nullptr;   // set by hstu_trace_set_fwd (trace builds only)
-#define HSTU_TRACE_DECL(ptr, on) unsigned long long* _trc = (unsigned long long*)(ptr); const bool _trc_on = (on); int _trc_i = 0
+struct TraceCtx { unsigned long long* p; bool on; int i; };
+#define HSTU_TRACE_DECL(ptr, on_) TraceCtx _tc{(unsigned long long*)(ptr), (on_), 0}
+#define HSTU_TRACE_ARG , TraceCtx& _tc
+#define HSTU_TRACE_PASS , _tc
 #define HSTU_MARK(tag)                                                                       \
   do {                                                                                       \
-    if (_trc_on && (threadIdx.x & 63) == 0 && _trc_i < 126) {                                \
-      _trc[(threadIdx.x >> 6) * 256 + 2 * _trc_i] = (unsigned long long)(tag);               \
-      _trc[(threadIdx.x >> 6) * 256 + 2 * _trc_i + 1] = __builtin_readcyclecounter();        \
-      ++_trc_i;                                                                              \
+    if (_tc.on && (threadIdx.x & 63) == 0 && _tc.i < 126) {                                  \
+      _tc.p[(threadIdx.x >> 6) * 256 + 2 * _tc.i] = (unsigned long long)(tag);               \
+      _tc.p[(threadIdx.x >> 6) * 256 + 2 * _tc.i + 1] = __builtin_readcyclecounter();        \
+      ++_tc.i;                                                                               \
     }                                                                                        \
   } while (0)
 #else
 #define HSTU_TRACE_DECL(ptr, on)
+#define HSTU_TRACE_ARG
+#define HSTU_TRACE_PASS
 #define HSTU_MARK(tag)
 #endif
 

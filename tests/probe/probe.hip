@@ -22,6 +22,20 @@ __global__ void probe_mfma_bf16(const uint16_t* A, const uint16_t* B, float* Cre
   for (int r = 0; r < 16; ++r) Cregs[l * 16 + r] = c[r];
 }
 
+// 16x16x32 bf16: lane l supplies A[l&15][8*(l>>4) + j], B[8*(l>>4) + j][l&15]; writes its 4 accumulators.
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+__global__ void probe_mfma16_bf16(const uint16_t* A, const uint16_t* B, float* Cregs) {
+  const int l = threadIdx.x;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    a[j] = __builtin_bit_cast(__bf16, A[(l & 15) * 32 + 8 * (l >> 4) + j]);
+    b[j] = __builtin_bit_cast(__bf16, B[(8 * (l >> 4) + j) * 16 + (l & 15)]);
+  }
+  f32x4p c = {0, 0, 0, 0};
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) Cregs[l * 4 + r] = c[r];
+}
+
 // fp32 32x32x2: lane l supplies A[l&31][l>>5], B[l>>5][l&31]
 __global__ void probe_mfma_f32(const float* A, const float* B, float* Cregs) {
   const int l = threadIdx.x;
@@ -60,6 +74,10 @@ __global__ void probe_glds(const pu32x4* src, const int* perm, pu32x4* out) {
 extern "C" {
 int probe_run_mfma_bf16(const void* A, const void* B, void* C, void* stream) {
   hipLaunchKernelGGL(probe_mfma_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (float*)C);
+  return (int)hipGetLastError();
+}
+int probe_run_mfma16_bf16(const void* A, const void* B, void* C, void* stream) {
+  hipLaunchKernelGGL(probe_mfma16_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (float*)C);
   return (int)hipGetLastError();
 }
 int probe_run_mfma_f32(const void* A, const void* B, void* C, void* stream) {

@@ -346,3 +346,56 @@ def test_torch_library_operator_seam():
     with pytest.raises(RuntimeError, match="attn_scale"):
         torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach(), k.detach(), v.detach(), off, True, nt,
                                     torch.ones(1, device=DEV), 0, 0, 0, None, None, None, 0)
+
+
+# ------------------------------------------------------------------ folded backward schedule (short sequences, d in {64, 128})
+FOLD_LENGTHS = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 200, 223, 224]
+
+
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("variant", ["causal", "targets", "window", "targets+window+full"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fold_backward_every_tile_count(d, variant, dtype):
+    """hstu_attn_bwd_fold.cuh: 1..7 tiles per user (odd and even tile counts take different hand-over
+    paths), lengths on both sides of every tile boundary, mixed in one batch so that every workgroup
+    has its own step count; every mask the schedule supports (no contextual rows)."""
+    rng = np.random.default_rng(d + len(variant))
+    lengths = np.array(FOLD_LENGTHS, dtype=np.int64)
+    rng.shuffle(lengths)
+    B, H = len(lengths), 2
+    targets = "targets" in variant
+    nt = np.minimum(rng.integers(1, 40, size=B), lengths).astype(np.int64) if targets else None
+    off = np.zeros(B + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lengths)
+    L = int(off[-1])
+    c = dict(N=224, alpha=1.0 / d**0.5, off=off, nt=nt, w=37 if "window" in variant else 0, ctx=0,
+             mf=50 if "full" in variant else 0,
+             q=rng.uniform(-1, 1, (L, H, d)), k=rng.uniform(-1, 1, (L, H, d)), v=rng.uniform(-1, 1, (L, H, d)),
+             dout=rng.standard_normal((L, H, d)))
+    _run_case(c, dtype)
+
+
+def test_fold_backward_strided_fused_views_metric_shape():
+    """metric shape (N = 200, H = 4, d = 128, bf16) on column slices of fused (L, H, 3d) buffers, the layout
+    the STU layer and bench.py hand to the kernels; dq/dk/dv written through strided views as well."""
+    from generative_recommenders_amd.ops import _launch
+
+    rng = np.random.default_rng(11)
+    B, H, d, N = 5, 4, 128, 200
+    lengths = np.array([200, 200, 137, 200, 64], dtype=np.int64)
+    off = np.zeros(B + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lengths)
+    L = int(off[-1])
+    fused = torch.from_numpy(rng.uniform(-1, 1, (L, H, 3 * d))).to(DEV).to(torch.bfloat16)
+    q, k, v = torch.split(fused, [d, d, d], dim=-1)
+    do = torch.from_numpy(rng.standard_normal((L, H, d))).to(DEV).to(torch.bfloat16)
+    offs = torch.from_numpy(off).to(DEV)
+    dfused = torch.zeros_like(fused)
+    gq, gk, gv = torch.split(dfused, [d, d, d], dim=-1)
+    dq, dk, dv = _launch.attn_bwd(do, q, k, v, offs, None, N, d**-0.5, 1.0 / N, dq=gq, dk=gk, dv=gv)
+    assert dq.data_ptr() == gq.data_ptr()
+    rq, rk, rv = O.hstu_mha_bwd(N, d**-0.5, do.double().cpu().numpy(), q.double().cpu().numpy(), k.double().cpu().numpy(),
+                                v.double().cpu().numpy(), off)
+    check_close(dq, rq, torch.bfloat16, "dq")
+    check_close(dk, rk, torch.bfloat16, "dk")
+    check_close(dv, rv, torch.bfloat16, "dv")

@@ -62,6 +62,29 @@ def test_mfma_bf16_32x32x16_layout():
     assert np.array_equal(got, exp)
 
 
+def test_mfma_bf16_16x16x32_layout():
+    """dQ GEMM of the folded backward: A[m = l&15][k = 8 (l>>4) + j], B[k][n = l&15], C[m = 4 (l>>4) + r][n = l&15]."""
+    lib = _probe()
+    g = torch.Generator().manual_seed(2)
+    A = torch.randint(-4, 5, (16, 32), generator=g).float()
+    B = torch.randint(-4, 5, (32, 16), generator=g).float()
+    Ab = A.to(torch.bfloat16).view(torch.int16).cuda()
+    Bb = B.to(torch.bfloat16).view(torch.int16).cuda()
+    out = torch.zeros(64 * 4, device="cuda")
+    assert lib.probe_run_mfma16_bf16(C.c_void_p(Ab.data_ptr()), C.c_void_p(Bb.data_ptr()), C.c_void_p(out.data_ptr()), _stream()) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().view(64, 4).numpy()
+    ref = (A @ B).numpy()
+    exp = np.zeros((64, 4), dtype=np.float32)
+    for l in range(64):
+        for r in range(4):
+            exp[l, r] = ref[4 * (l >> 4) + r, l & 15]
+    if not np.array_equal(got, exp):
+        _dump("probe_mfma16_bf16_got.npy", got)
+        _dump("probe_mfma16_bf16_ref.npy", ref)
+    assert np.array_equal(got, exp)
+
+
 def test_mfma_f32_32x32x2_layout():
     lib = _probe()
     g = torch.Generator().manual_seed(1)

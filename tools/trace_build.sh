@@ -3,8 +3,8 @@
 set -e
 cd "$(dirname "$0")/../generative_recommenders_amd/csrc"
 mkdir -p build_trace
-for f in capi attn_misc attn_bf16 attn_bias_bf16 jagged_ops norm_ops; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHSTU_TRACE -I. -I../../include -c $f.hip -o build_trace/$f.o &
+for f in capi attn_misc attn_bf16 attn_bias_bf16 attn_fold_bf16 jagged_ops norm_ops; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHSTU_TRACE $HSTU_EXTRA -I. -I../../include -c $f.hip -o build_trace/$f.o &
 done
 wait
 cat > build_trace/stubs.cpp <<'EOS'
@@ -20,6 +20,7 @@ int launch_attn_fwd_bias_f16(const HstuAttnParams&, hipStream_t) { return -2; }
 int launch_attn_fwd_bias_f32(const HstuAttnParams&, hipStream_t) { return -2; }
 int launch_attn_bwd_bias_f16(const HstuAttnBwdParams&, hipStream_t) { return -2; }
 int launch_attn_bwd_bias_f32(const HstuAttnBwdParams&, hipStream_t) { return -2; }
+int launch_attn_bwd_fold_f16(const HstuAttnBwdParams&, hipStream_t) { return -2; }
 }
 EOS
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -I../../include -c build_trace/stubs.cpp -o build_trace/stubs.o

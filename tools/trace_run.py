@@ -39,7 +39,7 @@ def dump(t, names, waves):
             tag, ts = int(t[w, i, 0]), int(t[w, i, 1])
             if tag == 0:
                 break
-            print(f"  {names.get(tag, tag):>18s}  t={ts - t0:8d}  (+{ts - prev})")
+            print(f"  {str(names.get(tag, tag)):>18s}  t={ts - t0:8d}  (+{ts - prev})")
             prev = ts
 
 ftrace = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
@@ -57,16 +57,16 @@ dump(ftrace.cpu().view(8, 128, 2).numpy(), {1: "start", 2: "Q issued+done", 3: "
      21: "end"}, (0, 2, 3))
 print("===== BACKWARD (workgroup 4096)")
 t = trace.cpu().view(8, 128, 2).numpy()
-names = {1: "start", 2: "kv_loaded_issued", 3: "stage0_ready", 10: "step_begin", 11: "S,dP done", 12: "elementwise done",
-         13: "dV,dK done", 14: "publish done", 15: "barrier1 passed", 16: "stage written", 17: "phase2 done",
-         18: "barrier2 passed", 20: "loop done", 21: "end"}
+names = {1: "start", 2: "dma issued", 3: "stage0_ready", 10: "step top barrier passed", 11: "S,dP done", 12: "elementwise done",
+         13: "pair done", 14: "diag store done", 15: "barrier1 passed", 16: "dQ gemm done", 17: "dQ stored",
+         18: "stage dma issued", 19: "dq setup done", 20: "loop done", 21: "end", 22: "dump barrier passed", 23: "dV parked", 24: "final tiles parked"}
 t0 = min(int(t[w, 0, 1]) for w in range(8) if t[w, 0, 0])
-for w in (0, 3, 6, 7):
+for w in (0, 3, 5, 7):
     print(f"--- wave {w}")
     prev = t0
     for i in range(128):
         tag, ts = int(t[w, i, 0]), int(t[w, i, 1])
         if tag == 0:
             break
-        print(f"  {names.get(tag, tag):>18s}  t={ts - t0:8d}  (+{ts - prev})")
+        print(f"  {str(names.get(tag, tag)):>18s}  t={ts - t0:8d}  (+{ts - prev})")
         prev = ts
