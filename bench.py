@@ -200,6 +200,13 @@ def cpu_baseline(args):
                        f"({med * 1e3:.0f} ms each); oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
 
 
+def bwd_kernel_name(args) -> str:
+    """which backward kernel the library dispatches for this shape (csrc/attn_misc.hip: attn_bwd_fold_applicable)"""
+    fold = (args.head_dim in (64, 128) and (args.max_seq_len + 31) // 32 <= 7
+            and os.environ.get("HSTU_BWD_FOLD", "1")[:1] != "0")
+    return f"hstu_attn_bwd_{'fold_' if fold else ''}kernel<bf16,{args.head_dim},{args.head_dim}>"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,7 +258,7 @@ def main():
             "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "parallelism": f"dp{world} (no collective: attention has no parameters)",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "hstu_attn_bwd_kernel<bf16,128,128>",
+            "bound": "hbm", "kernel": bwd_kernel_name(args),
             "achieved": att["bwd_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att["bwd_gbps"] / HBM_PEAK_GBPS,
             "traffic": None, "algorithmic_bytes_per_launch": att["bwd_bytes"], "avg_launch_ms": att["bwd_ms"],
         },
