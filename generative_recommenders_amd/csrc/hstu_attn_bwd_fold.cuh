@@ -30,6 +30,10 @@
 #define FOLD_DQ_DEPTH 1   // slots of transposed reads in flight ahead of the MFMAs (2 spills registers)
 #endif
 
+#ifndef FOLD_SDP_AHEAD
+#define FOLD_SDP_AHEAD 3   // MFMAs whose LDS operands are requested ahead in the S / dP stream
+#endif
+
 namespace hstu {
 
 template <typename T, int DQK, int DV>
@@ -91,19 +95,29 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
   f32x16 s, dp;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+  // S and dP as ONE stream of 16 MFMAs alternating between the two accumulators (no back-to-back dependency), with
+  // the LDS reads of item m + AHEAD issued before the MFMA of item m.  The order is pinned with scheduling
+  // barriers: left alone, hipcc emits read, read, wait, MFMA per item into the same registers, i.e. one full LDS
+  // latency per MFMA, and the pair is latency bound whoever shares the SIMD.
+  static_assert(DQK == DV, "interleaved S / dP stream");
+  {
+    constexpr int NM = 2 * C::KGQ, AHEAD = FOLD_SDP_AHEAD;
+    Frag fa[AHEAD + 1], fb[AHEAD + 1];
+    auto load_item = [&](int m, Frag& a, Frag& bb) {
+      const int e0 = hf * (DQK / 2) + (m >> 1) * 8;
+      a = lds_row_frag<T, C::UPR_K>((m & 1) ? dOs : Qs, n32, e0);
+      bb = lds_row_frag<T, C::UPR_K>((m & 1) ? Vw : Kw, n32, e0);
+    };
 #pragma unroll
-  for (int kg = 0; kg < C::KGQ; ++kg) {
-    const int e0 = hf * (DQK / 2) + kg * 8;
-    Frag a = lds_row_frag<T, C::UPR_K>(Qs, n32, e0);
-    Frag bb = lds_row_frag<T, C::UPR_K>(Kw, n32, e0);
-    s = E::mma(a, bb, s);
-  }
+    for (int m = 0; m < AHEAD; ++m) load_item(m, fa[m % (AHEAD + 1)], fb[m % (AHEAD + 1)]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int kg = 0; kg < C::KGV; ++kg) {
-    const int e0 = hf * (DV / 2) + kg * 8;
-    Frag a = lds_row_frag<T, C::UPR_V>(dOs, n32, e0);
-    Frag bb = lds_row_frag<T, C::UPR_V>(Vw, n32, e0);
-    dp = E::mma(a, bb, dp);
+    for (int m = 0; m < NM; ++m) {
+      if (m + AHEAD < NM) load_item(m + AHEAD, fa[(m + AHEAD) % (AHEAD + 1)], fb[(m + AHEAD) % (AHEAD + 1)]);
+      if (m & 1) dp = E::mma(fa[m % (AHEAD + 1)], fb[m % (AHEAD + 1)], dp);
+      else s = E::mma(fa[m % (AHEAD + 1)], fb[m % (AHEAD + 1)], s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   HSTU_MARK(11);
   // C layout: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf.  Query rows >= len
@@ -151,22 +165,28 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
     dsb[h8] = E::pack8(dsv);
   }
   HSTU_MARK(12);
-  // dV_w^T[dv][key] += dO_i^T[dv][q] P'[q][key]
+  // dV_w^T[dv][key] += dO_i^T[dv][q] P'[q][key]   and   dK_w^T[d][key] += Q_i^T[d][q] dS'[q][key]:
+  // one stream of 16 MFMAs alternating between the dV and dK accumulators, A fragments (transposed LDS reads of
+  // the dO / Q tile) requested AHEAD items before their MFMA, order pinned as above
+  {
+    constexpr int NM = 2 * 2 * C::DBQ, AHEAD = FOLD_SDP_AHEAD;   // (dV | dK) x d block x k half
+    Frag fa[AHEAD + 1];
+    auto load_item = [&](int m, Frag& a) {
+      const int ks = (m >> 1) & 1, d = m >> 2;
+      a = lds_col_frag<T, C::UPR_K>((m & 1) ? Qs : dOs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+    };
 #pragma unroll
-  for (int d = 0; d < C::DBV; ++d)
+    for (int m = 0; m < AHEAD; ++m) load_item(m, fa[m % (AHEAD + 1)]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Frag a = lds_col_frag<T, C::UPR_V>(dOs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
-      dv_acc[d] = E::mma(a, pb[ks], dv_acc[d]);
+    for (int m = 0; m < NM; ++m) {
+      if (m + AHEAD < NM) load_item(m + AHEAD, fa[(m + AHEAD) % (AHEAD + 1)]);
+      const int ks = (m >> 1) & 1, d = m >> 2;
+      if (m & 1) dk_acc[d] = E::mma(fa[m % (AHEAD + 1)], dsb[ks], dk_acc[d]);
+      else dv_acc[d] = E::mma(fa[m % (AHEAD + 1)], pb[ks], dv_acc[d]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  // dK_w^T[d][key] += Q_i^T[d][q] dS'[q][key]
-#pragma unroll
-  for (int d = 0; d < C::DBQ; ++d)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Frag a = lds_col_frag<T, C::UPR_K>(Qs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
-      dk_acc[d] = E::mma(a, dsb[ks], dk_acc[d]);
-    }
+  }
   // publish dS' as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3) = chunk hf + 2 rq
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
@@ -331,7 +351,7 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 }
 
 template <typename T, int DQK, int DV>
-__global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_fold_kernel(const HstuAttnBwdParams bp, int tmax) {
+__global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void hstu_attn_bwd_fold_kernel(const HstuAttnBwdParams bp, int tmax) {
   using C = BwdCfg<T, DQK, DV>;
   using F = FoldCfg<T, DQK, DV>;
   static_assert(C::EB == 2, "the folded backward is built for 16-bit I/O");
