@@ -18,7 +18,7 @@ constexpr int kNormThreads = 256;
 constexpr int kNormWaves = kNormThreads / 64;
 // register-resident pieces per lane: 16-bit x8 -> dim <= 1024, fp32 x4 -> dim <= 1024, scalar -> dim <= 512
 template <int VEC> constexpr int max_chunks() { return VEC == 8 ? 2 : (VEC == 4 ? 4 : 8); }
-constexpr int kMaxNormBlocks = 1024;
+constexpr int kMaxNormBlocks = 2048;
 
 template <typename T, int VEC> struct RowVec {
   float v[VEC];
@@ -195,13 +195,26 @@ __global__ __launch_bounds__(kNormThreads) void layer_norm_bwd_kernel(const T* d
   block_reduce_cols<VEC>(db, lds, partial + (int64_t)blockIdx.x * 2 * dim + dim, dim, nch);
 }
 
-// sums `nparts` partial rows of width `width` -> out[width]
-__global__ void reduce_partials_kernel(const float* partial, int nparts, int stride, int width, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= width) return;
+// Column sums of the (nparts, 2 * width) partial matrix: columns [0, width) -> out_w, [width, 2 width) -> out_b.
+// One 256-thread block per column: thread t adds rows t, t + 256, ... in a fixed order, then the block combines
+// the 256 sums in a fixed tree (deterministic).  (One thread per column walking all the rows is latency bound:
+// with group norm the width is the number of heads, i.e. 4 threads for ~1000 dependent loads.)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int nparts, int width, float* out_w,
+                                                              float* out_b) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int i = 0; i < nparts; ++i) s += partial[(int64_t)i * stride + c];
-  out[c] = s;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partial[(int64_t)i * (2 * width) + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (c < width) out_w[c] = red[0];
+    else out_b[c - width] = red[0];
+  }
 }
 
 // ------------------------------------------------------------------ y = u * Norm(attn) [, concat]
@@ -389,6 +402,172 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_kernel(const T* dy,
   }
 }
 
+// ------------------------------------------------------------------ group norm * u, fast path
+// Group norm with head_dim / VEC lanes per head (a power of two <= 64, e.g. 128 / 8 = 16): every lane's 16-byte
+// piece lies inside ONE head, so all heads of a row are normalised at once with segmented (xor-shuffle) sums over
+// the lanes of a head.  The general kernels above walk the heads one after the other with the other lanes
+// masked (heads x the arithmetic) and fetch the concat slots in a second round trip per row.
+HSTU_DEV float seg_sum(float x, int lanes_per_head) {
+  for (int d = 1; d < lanes_per_head; d <<= 1) x += __shfl_xor(x, d, 64);
+  return x;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kNormThreads) void norm_mul_fwd_gn_kernel(const T* attn, const T* u, const T* w, const T* b,
+                                                                       T* y, float* mean_out, float* rstd_out,
+                                                                       int64_t rows, int heads, int hdim, float eps,
+                                                                       int concat) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = heads * hdim;
+  const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
+  const int lph = hdim / VEC;
+  const int ostride = concat ? 3 * dim : dim;
+  const float inv = 1.0f / hdim;
+  for (int64_t row = (int64_t)blockIdx.x * kNormWaves + wave; row < rows; row += (int64_t)gridDim.x * kNormWaves) {
+    RowVec<T, VEC> xv[max_chunks<VEC>()], uv[max_chunks<VEC>()];
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      const bool ok = k < nch && c < dim;
+      load_vec<T, VEC>(xv[k], attn + row * dim + c, ok);
+      load_vec<T, VEC>(uv[k], u + row * dim + c, ok);
+    }
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      if (k < nch) {               // wave-uniform; lanes past dim take part in the shuffles with zeros
+        const bool ok = c < dim;
+        const int h = ok ? c / hdim : 0;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s += xv[k].v[i];
+        const float mean = seg_sum(s, lph) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const float d = xv[k].v[i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(seg_sum(q, lph) * inv + eps);
+        if (ok) {
+          const float gw = (float)w[h], gb = (float)b[h];
+          RowVec<T, VEC> o;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o.v[i] = uv[k].v[i] * ((xv[k].v[i] - mean) * rstd * gw + gb);
+          T* yrow = y + row * ostride;
+          if (concat) {
+            store_vec<T, VEC>(uv[k], yrow + c);
+            store_vec<T, VEC>(xv[k], yrow + dim + c);
+            store_vec<T, VEC>(o, yrow + 2 * dim + c);
+          } else {
+            store_vec<T, VEC>(o, yrow + c);
+          }
+          if (c % hdim == 0) {
+            if (mean_out) mean_out[row * heads + h] = mean;
+            if (rstd_out) rstd_out[row * heads + h] = rstd;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_gn_kernel(const T* dy, const T* attn, const T* u, const T* w,
+                                                                       const T* b, const float* mean_in,
+                                                                       const float* rstd_in, T* dattn, T* du,
+                                                                       float* partial, int64_t rows, int heads, int hdim,
+                                                                       int concat) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = heads * hdim;
+  const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
+  const int lph = hdim / VEC;
+  const int istride = concat ? 3 * dim : dim;
+  const float inv = 1.0f / hdim;
+  // this lane's head per chunk never changes: its dweight / dbias partial sums stay in two registers per chunk
+  float hw[max_chunks<VEC>()], hb[max_chunks<VEC>()], gw[max_chunks<VEC>()], gb[max_chunks<VEC>()];
+  int head[max_chunks<VEC>()];
+#pragma unroll
+  for (int k = 0; k < max_chunks<VEC>(); ++k) {
+    const int c = (k * 64 + lane) * VEC;
+    const bool ok = k < nch && c < dim;
+    head[k] = ok ? c / hdim : 0;
+    gw[k] = ok ? (float)w[head[k]] : 0.f;
+    gb[k] = ok ? (float)b[head[k]] : 0.f;
+    hw[k] = 0.f;
+    hb[k] = 0.f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * kNormWaves + wave; row < rows; row += (int64_t)gridDim.x * kNormWaves) {
+    RowVec<T, VEC> xv[max_chunks<VEC>()], uv[max_chunks<VEC>()], gy[max_chunks<VEC>()], e1[max_chunks<VEC>()], e2[max_chunks<VEC>()];
+    float mean[max_chunks<VEC>()], rstd[max_chunks<VEC>()];
+    const T* dyrow = dy + row * istride;
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {   // every load of the row is issued before anything is used
+      const int c = (k * 64 + lane) * VEC;
+      const bool ok = k < nch && c < dim;
+      load_vec<T, VEC>(xv[k], attn + row * dim + c, ok);
+      load_vec<T, VEC>(uv[k], u + row * dim + c, ok);
+      load_vec<T, VEC>(gy[k], dyrow + (concat ? 2 * dim : 0) + c, ok);
+      load_vec<T, VEC>(e1[k], dyrow + c, ok && concat);           // d u    from the concat slot
+      load_vec<T, VEC>(e2[k], dyrow + dim + c, ok && concat);     // d attn from the concat slot
+      mean[k] = ok ? mean_in[row * heads + head[k]] : 0.f;
+      rstd[k] = ok ? rstd_in[row * heads + head[k]] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      if (k < nch) {
+        const bool ok = c < dim;
+        float s1 = 0.f, s2 = 0.f;
+        RowVec<T, VEC> gg, xh, o, o2;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float xhat = (xv[k].v[i] - mean[k]) * rstd[k];
+          const float dyu = gy[k].v[i] * uv[k].v[i];               // d(norm out)
+          xh.v[i] = xhat;
+          gg.v[i] = dyu * gw[k];
+          s1 += gg.v[i] * xhat;
+          s2 += gg.v[i];
+          hw[k] += dyu * xhat;
+          hb[k] += dyu;
+          o2.v[i] = gy[k].v[i] * (gw[k] * xhat + gb[k]) + e1[k].v[i];
+        }
+        const float c1 = seg_sum(s1, lph) * inv, c2 = seg_sum(s2, lph) * inv;
+        if (ok) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o.v[i] = rstd[k] * (gg.v[i] - c2 - xh.v[i] * c1) + e2[k].v[i];
+          store_vec<T, VEC>(o, dattn + row * dim + c);
+          store_vec<T, VEC>(o2, du + row * dim + c);
+        }
+      }
+    }
+  }
+  // per-head partials: lanes of a head -> its first lane -> LDS[wave][head] (a head lives in exactly one chunk) ->
+  // fixed-order sum over the waves
+  for (int i = threadIdx.x; i < kNormWaves * 32; i += kNormThreads) lds[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < max_chunks<VEC>(); ++k) {
+    const int c = (k * 64 + lane) * VEC;
+    if (k < nch) {
+      const float a = seg_sum(hw[k], lph), cc = seg_sum(hb[k], lph);
+      if (c < dim && c % hdim == 0) { lds[wave * 32 + head[k]] = a; lds[wave * 32 + 16 + head[k]] = cc; }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < heads) {
+    float a = 0.f, cc = 0.f;
+    for (int w2 = 0; w2 < kNormWaves; ++w2) { a += lds[w2 * 32 + threadIdx.x]; cc += lds[w2 * 32 + 16 + threadIdx.x]; }
+    float* out_row = partial + (int64_t)blockIdx.x * 2 * heads;
+    out_row[threadIdx.x] = a;
+    out_row[heads + threadIdx.x] = cc;
+  }
+}
+
+static bool gn_fast_ok(int hdim, int v) {
+  if (v <= 1 || hdim % v) return false;
+  const int lph = hdim / v;
+  return lph <= 64 && (lph & (lph - 1)) == 0;
+}
+
 // ------------------------------------------------------------------ SiLU on a column slice
 template <typename T, bool BWD>
 __global__ void silu_kernel(const T* dout, const T* in, T* out, int64_t rows, int cols, int64_t s_dout, int64_t s_in,
@@ -450,8 +629,7 @@ static int ln_bwd(const void* dy, const void* x, const void* w, const float* mea
   else
     hipLaunchKernelGGL((layer_norm_bwd_kernel<T, (sizeof(T) == 2 ? 8 : 4)>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)x, (const T*)w, mean, rstd, (T*)dx, partial, rows, dim);
   if (int e = check_launch("layer_norm_bwd")) return e;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, partial, nb, 2 * dim, dim, dweight);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, partial + dim, nb, 2 * dim, dim, dbias);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * dim), dim3(256), 0, st, partial, nb, dim, dweight, dbias);
   return check_launch("layer_norm_bwd(reduce)");
 }
 
@@ -467,7 +645,9 @@ static int nm_fwd(const void* attn, const void* u, const void* w, const void* b,
   const int nb = norm_blocks(rows);
 #define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_fwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, heads, hdim, eps, concat)
   constexpr int VV = sizeof(T) == 2 ? 8 : 4;
-  if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
+  if (gn && gn_fast_ok(hdim, v))
+    hipLaunchKernelGGL((norm_mul_fwd_gn_kernel<T, VV>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, heads, hdim, eps, concat);
+  else if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
   else { if (gn) NM_LAUNCH(VV, true); else NM_LAUNCH(VV, false); }
 #undef NM_LAUNCH
   return check_launch("norm_mul_fwd");
@@ -489,13 +669,14 @@ static int nm_bwd(const void* dy, const void* attn, const void* u, const void* w
   const size_t lds = gn ? kNormWaves * 32 * sizeof(float) : (size_t)kNormWaves * nch * 64 * v * sizeof(float);
 #define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_bwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, mean, rstd, (T*)dattn, (T*)du, partial, rows, heads, hdim, concat)
   constexpr int VV = sizeof(T) == 2 ? 8 : 4;
-  if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
+  if (gn && gn_fast_ok(hdim, v))
+    hipLaunchKernelGGL((norm_mul_bwd_gn_kernel<T, VV>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, mean, rstd, (T*)dattn, (T*)du, partial, rows, heads, hdim, concat);
+  else if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
   else { if (gn) NM_LAUNCH(VV, true); else NM_LAUNCH(VV, false); }
 #undef NM_LAUNCH
   if (int e = check_launch("norm_mul_bwd")) return e;
   const int width = gn ? heads : dim;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, st, partial, nb, 2 * width, width, dweight);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, st, partial + width, nb, 2 * width, width, dbias);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * width), dim3(256), 0, st, partial, nb, width, dweight, dbias);
   return check_launch("norm_mul_bwd(reduce)");
 }
 
