@@ -18,6 +18,7 @@ from generative_recommenders_amd.common import HammerKernel
 from generative_recommenders_amd.ops import _launch
 from generative_recommenders_amd.ops.hstu_attention import hstu_mha
 from generative_recommenders_amd.ops.layer_norm import layer_norm
+from generative_recommenders_amd.ops.mm import weight_grad_mm
 
 
 def hstu_compute_uqvk(
@@ -103,7 +104,7 @@ class _ComputeOutputFunction(torch.autograd.Function):
             y = ctx.saved_tensors[7]
         dout = dout.contiguous()
         dy = torch.mm(dout, Wo.t())
-        dWo = torch.mm(y.t(), dout)
+        dWo = weight_grad_mm(y, dout)
         dattn, du, dnw, dnb = _launch.norm_mul_bwd(dy, attn, u, nw, nb, mean, rstd, H, Ld, gn, cat)
         return dattn, du, dout, dnw.to(nw.dtype), dnb.to(nb.dtype), dWo, None, None, None, None, None, None
 
@@ -197,7 +198,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                          dq=dq, dk=dk, dv=dv)
         _launch.silu_bwd(du, uvqk[:, :hv], din=duvqk[:, :hv])
         d_normed = torch.mm(duvqk, W.t())
-        dW = torch.mm(normed_x.t(), duvqk)
+        dW = weight_grad_mm(normed_x, duvqk)
         dbeta = duvqk.sum(dim=0)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
         return (dx, dnw.to(nw.dtype), dnb.to(nb.dtype), dW, dbeta.to(beta.dtype), None, None, None, None, None, None,

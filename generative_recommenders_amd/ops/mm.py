@@ -11,3 +11,42 @@ def addmm(input: torch.Tensor, mat1: torch.Tensor, mat2: torch.Tensor,
           kernel: HammerKernel = HammerKernel.HIP) -> torch.Tensor:
     del kernel
     return torch.addmm(input, mat1, mat2)
+
+
+_SPLIT_TARGET_TILES = 256          # one output tile per CU
+_bmm_f32_ok = None
+
+
+def _bmm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """batched a @ b with an fp32 result (hipBLASLt accumulates in fp32 anyway; this keeps the partial sums of the
+    split from being rounded to the activation dtype)."""
+    global _bmm_f32_ok
+    if _bmm_f32_ok is None:
+        try:
+            torch.bmm(a[:1, :8], b[:1, :, :8], out_dtype=torch.float32)
+            _bmm_f32_ok = True
+        except (TypeError, RuntimeError, NotImplementedError):
+            _bmm_f32_ok = False
+    if _bmm_f32_ok:
+        return torch.bmm(a, b, out_dtype=torch.float32)
+    return torch.bmm(a.float(), b.float())
+
+
+def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """``x^T dy`` for x (L, K), dy (L, N): the weight gradient of ``y = x W``.  The contraction runs over ALL jagged
+    rows (L ~ 10^5..10^6) while the result is one small (K, N) matrix: as a single GEMM that is K N / (128 x 256)
+    output tiles -- 32 workgroups on a 256-CU part for the DLRM-v3 projections.  The rows are therefore split into
+    S slabs, multiplied as one batched GEMM (S x as many tiles) with fp32 partial results, and summed."""
+    L, K = x.shape
+    N = dy.shape[1]
+    tiles = ((K + 127) // 128) * ((N + 255) // 256)
+    S = min(16, _SPLIT_TARGET_TILES // max(tiles, 1))
+    slab = (L // max(S, 1)) // 64 * 64
+    if not x.is_cuda or S <= 1 or slab < 2048:
+        return torch.mm(x.t(), dy)
+    main = slab * S
+    part = _bmm_f32(x[:main].view(S, slab, K).transpose(1, 2), dy[:main].view(S, slab, N))
+    out = part.sum(dim=0)
+    if main < L:
+        out += torch.mm(x[main:].t(), dy[main:]).float()
+    return out.to(x.dtype)
