@@ -128,6 +128,7 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
   if (mc.simple) mode = (k0 < i0 && i0 + 32 <= len) ? 0 : 1;    // strictly below the diagonal and all rows real
   else mode = (i0 + 32 <= len && mc.pair_fully_valid(i0, 32, k0, 32)) ? 0 : 2;
   const int key_id = mc.id_of(key);
+  const int key_bits = key_ok ? -1 : 0;
 #pragma unroll
   for (int h8 = 0; h8 < 2; ++h8) {
     float pv[8], dsv[8];
@@ -156,9 +157,9 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
       for (int j = 0; j < 8; ++j) {
         const int r = 8 * h8 + j;
         const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-        const bool ok = key_ok & (qi < len) & mc.valid_ids(qi, key, mc.id_of(qi), key_id);
-        pv[j] = ok ? pv[j] : 0.f;
-        dsv[j] = ok ? dsv[j] : 0.f;
+        const int keep = mc.keep_bits_noctx(qi, key, key_id) & key_bits;
+        pv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, pv[j]) & keep);
+        dsv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, dsv[j]) & keep);
       }
     }
     pb[h8] = E::pack8(pv);

@@ -215,6 +215,22 @@ struct MaskCtx {
     if (ctx > 0) m = m | ((idi == 0) & (idj < max_id));
     return m;
   }
+  // Same predicate as valid() & (i < len), as an all-ones / zero integer, for ctx == 0 (the folded backward):
+  // integer arithmetic only.  Compares would go through SGPR pairs and scalar and/or chains -- a VALU -> SALU ->
+  // VALU round trip per element.  `j` must be < len (the caller ANDs its own lane-constant key mask).
+  HSTU_DEV int keep_bits_noctx(int i, int j, int idj) const {
+    const int i_eff = i | ((len - 1 - i) >> 31);               // i, or -1 when i >= len
+    const int idi = has_targets ? min(i_eff, max_id) : i_eff;
+    const int d = idi - idj;
+    const int x = i_eff ^ j;
+    int m = (~(x | -x) >> 31) | ((-d) >> 31);                  // (i == j) | (d > 0)
+    if (win > 0) {                                             // wave-uniform
+      int in_win = (d - win - 1) >> 31;                        // d <= win
+      if (full > 0) in_win |= (max_id - full - 1 - idi) >> 31; // idi >= max_id - full
+      m &= in_win;
+    }
+    return m;
+  }
   // Is EVERY (i, j) with i in [i0, i0+ni), j in [j0, j0+nj), i,j < len valid?  (sufficient
   // condition; such tiles skip the per-element mask.  Query rows >= len need no mask: their
   // q / dO rows are zero-filled by the register staging path, so silu(0) = 0 and 0 * x = 0.)
