@@ -56,6 +56,10 @@ def attention_section(args, rank, world, device):
     dtype = torch.bfloat16
     fused = torch.empty(L, H, 3 * d, device=device, dtype=dtype).uniform_(-0.01, 0.01, generator=gen)
     q, k, v = torch.split(fused, [d, d, d], dim=-1)
+    if os.environ.get("HSTU_BENCH_LAYOUT") == "separate":   # experiment: contiguous (L, H, d) tensors
+        q, k, v = (t.contiguous() for t in (q, k, v))
+    elif os.environ.get("HSTU_BENCH_LAYOUT") == "headmajor":   # experiment: each head's rows contiguous (H, L, d)
+        q, k, v = (t.permute(1, 0, 2).contiguous().permute(1, 0, 2) for t in (q, k, v))
     dout = torch.randn(L, H, d, device=device, dtype=dtype, generator=gen)
     nt = None
     if args.workload == "M-targets":

@@ -273,7 +273,18 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     asm volatile("" ::: "memory");
     if (t + C::NS - 1 < ntiles) issue_tile(t + C::NS - 1);
     HSTU_MARK(10);
-    if (wave_active && mc.pair_may_be_active(r0 + i_shift, 32, j0, 32)) {
+    // (scalar work is not free: the general tile predicates cost ~100 SALU instructions per tile; plain-causal
+    // batches -- no targets, window or contextual rows -- take two compares instead)
+    const int i0w = r0 + i_shift;
+    bool tile_act, tile_full;
+    if (mc.simple) {
+      tile_act = i0w < len && j0 <= min(i0w + 31, len - 1);
+      tile_full = j0 + 32 <= i0w;     // strictly below this wave's first row (then also j0 + 32 <= len)
+    } else {
+      tile_act = mc.pair_may_be_active(i0w, 32, j0, 32);
+      tile_full = tile_act && mc.pair_fully_valid(i0w, 32, j0, 32);
+    }
+    if (wave_active && tile_act) {
       const char* Kt = smem + (t % C::NS) * C::STAGE;
       const char* Vt = Kt + C::KT;
       f32x16 s, s1;   // two accumulators halve the dependent-MFMA chain of the QK^T contraction
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       }
       HSTU_MARK(11);
       Frag pb[2];
-      const int mode = mc.pair_fully_valid(r0 + i_shift, 32, j0, 32) ? 0 : (mc.simple ? 1 : 2);   // wave-uniform
+      const int mode = tile_full ? 0 : (mc.simple ? 1 : 2);   // wave-uniform
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {   // two halves keep only 8 fp32 temporaries live
         float pv[8];

@@ -680,11 +680,44 @@ static int nm_bwd(const void* dy, const void* attn, const void* u, const void* w
   return check_launch("norm_mul_bwd(reduce)");
 }
 
+// 16 bytes per lane: a row of the column slice is `cols / VEC` pieces; used when the slice start, the row strides
+// and the width are all 16-byte multiples (the u slice of the fused uvqk buffer is)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void silu_vec_kernel(const T* dout, const T* in, T* out, int64_t rows, int cols,
+                                                       int64_t s_dout, int64_t s_in, int64_t s_out) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int ppr = cols / VEC;                               // pieces per row
+  const int64_t n = rows * ppr;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ppr;
+    const int c = (int)(i - r * ppr) * VEC;
+    RowVec<T, VEC> x, g, o;
+    load_vec<T, VEC>(x, in + r * s_in + c, true);
+    if (BWD) load_vec<T, VEC>(g, dout + r * s_dout + c, true);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float sg = 1.0f / (1.0f + __expf(-x.v[k]));
+      o.v[k] = BWD ? g.v[k] * sg * (1.f + x.v[k] * (1.f - sg)) : x.v[k] * sg;
+    }
+    store_vec<T, VEC>(o, out + r * s_out + c);
+  }
+}
+
 template <typename T, bool BWD>
 static int silu_launch(const void* dout, const void* in, void* out, int64_t rows, int cols, int64_t s0, int64_t s1,
                        int64_t s2, hipStream_t st) {
   const int64_t n = rows * cols;
   if (n == 0) return HSTU_OK;
+  constexpr int VEC = 16 / sizeof(T);
+  const bool vec_ok = cols % VEC == 0 && s1 % VEC == 0 && s2 % VEC == 0 && (!BWD || s0 % VEC == 0) &&
+                      (((uintptr_t)in | (uintptr_t)out | (BWD ? (uintptr_t)dout : 0)) & 15) == 0;
+  if (vec_ok) {
+    const int64_t pieces = n / VEC;
+    int blocks = (int)((pieces + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((silu_vec_kernel<T, BWD>), dim3(blocks), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)out, rows, cols, s0, s1, s2);
+    return check_launch("silu");
+  }
   int blocks = (int)((n + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL((silu_kernel<T, BWD>), dim3(blocks), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)out, rows, cols, s0, s1, s2);

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table for the HBM-bound helper kernels of the path: algorithmic
+bytes / HIP-event time vs the 8 TB/s HBM peak, at the DLRM-v3 layer shape (1024 users, L ~ U[180,200), D = 512, bf16).
+Prints one JSON object (also the torch CPU time of the same op on a bounded sample, as the CPU leg).
+Run on the GPU box:  python tools/bench_ops.py > gpurun_out/bench_ops.json"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from generative_recommenders_amd.ops import _launch
+
+PEAK = 8000.0
+dev = "cuda"
+torch.manual_seed(0)
+B, N, D, H = 1024, 200, 512, 4
+lengths = torch.randint(180, 200, (B,), device=dev)
+off = _launch.complete_cumsum(lengths)
+L = int(off[-1])
+bf = torch.bfloat16
+x = torch.randn(L, D, device=dev, dtype=bf)
+dy = torch.randn(L, D, device=dev, dtype=bf)
+w = torch.ones(D, device=dev, dtype=bf); b = torch.zeros(D, device=dev, dtype=bf)
+gw = torch.ones(H, device=dev, dtype=bf); gb = torch.zeros(H, device=dev, dtype=bf)
+u = torch.randn(L, D, device=dev, dtype=bf)
+dy3 = torch.randn(L, 3 * D, device=dev, dtype=bf)
+uvqk = torch.randn(L, 4 * D, device=dev, dtype=bf)
+lens_r = torch.randint(1, 21, (B,), device=dev)
+off_r = _launch.complete_cumsum(lens_r)
+xr = torch.randn(int(off_r[-1]), D, device=dev, dtype=bf)
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+es = 2
+y_ln, mean, rstd = _launch.layer_norm_fwd(x, w, b, 1e-6)
+y_nm, m2, r2 = _launch.norm_mul_fwd(x, u, gw, gb, 1e-6, H, D // H, True, True)
+cat = _launch.concat_2d_jagged(x, xr, off, off_r, N, 20, N + 20)
+dense = _launch.jagged_to_padded_dense(x, off, N)
+rows = {
+    "complete_cumsum (B=1024, int64)": (lambda: _launch.complete_cumsum(lengths), 2 * B * 8),
+    "layer_norm_fwd": (lambda: _launch.layer_norm_fwd(x, w, b, 1e-6), 2 * L * D * es),
+    "layer_norm_bwd": (lambda: _launch.layer_norm_bwd(dy, x, w, mean, rstd), 3 * L * D * es),
+    "norm_mul_fwd (group norm, concat [u, attn, y])": (lambda: _launch.norm_mul_fwd(x, u, gw, gb, 1e-6, H, D // H, True, True), 5 * L * D * es),
+    "norm_mul_bwd (group norm, concat)": (lambda: _launch.norm_mul_bwd(dy3, x, u, gw, gb, m2, r2, H, D // H, True, True), 7 * L * D * es),
+    "silu_fwd on the u slice of uvqk": (lambda: _launch.silu_fwd(uvqk[:, :D]), 2 * L * D * es),
+    "concat_2d_jagged (history + targets)": (lambda: _launch.concat_2d_jagged(x, xr, off, off_r, N, 20, N + 20), 2 * (L + xr.shape[0]) * D * es),
+    "split_2d_jagged": (lambda: _launch.split_2d_jagged(cat, L, xr.shape[0], off, off_r, N, 20, N + 20), 2 * (L + xr.shape[0]) * D * es),
+    "jagged_to_padded_dense": (lambda: _launch.jagged_to_padded_dense(x, off, N), L * D * es + B * N * D * es),
+    "dense_to_jagged": (lambda: _launch.dense_to_jagged(dense, off, L), 2 * L * D * es),
+}
+out = {"shape": {"users": B, "rows": L, "D": D, "heads": H, "dtype": "bf16"}, "peak_GBps": PEAK, "kernels": {}}
+for name, (fn, nbytes) in rows.items():
+    t = timed(fn)
+    out["kernels"][name] = {"us": round(t * 1e6, 1), "algorithmic_bytes": nbytes, "GBps": round(nbytes / t / 1e9, 1),
+                            "frac_of_hbm_peak": round(nbytes / t / 1e9 / PEAK, 3)}
+# CPU leg: the torch CPU equivalents of the two heaviest row kernels on a 128-user sample
+torch.set_num_threads(min(32, os.cpu_count() or 1))
+n = int(off[128])
+xc, uc = x[:n].float().cpu(), u[:n].float().cpu()
+t0 = time.perf_counter()
+for _ in range(3):
+    yc = torch.nn.functional.layer_norm(xc, (D,), eps=1e-6)
+t_ln = (time.perf_counter() - t0) / 3
+t0 = time.perf_counter()
+for _ in range(3):
+    g = torch.nn.functional.group_norm(xc.view(n, H, D // H).transpose(1, 2).reshape(n, D // H * H)[:, :, None].reshape(n, D, 1)[:, :, 0].view(n, H, D // H), H) if False else torch.nn.functional.layer_norm(xc.view(n, H, D // H), (D // H,), eps=1e-6).view(n, D)
+    yc = torch.cat([uc, xc, uc * g], dim=1)
+t_nm = (time.perf_counter() - t0) / 3
+out["cpu_reference"] = {"sample_rows": n, "threads": torch.get_num_threads(),
+                        "layer_norm_fwd_GBps": round(2 * n * D * 4 / t_ln / 1e9, 2),
+                        "norm_mul_fwd_GBps": round(5 * n * D * 4 / t_nm / 1e9, 2)}
+print(json.dumps(out, indent=1))
