@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 2
+#define HSTU_ABI_VERSION 3
 
 enum {
   HSTU_OK = 0,
@@ -219,6 +219,25 @@ int hstu_silu_fwd(const void* in, void* out, int64_t rows, int32_t cols,
 int hstu_silu_bwd(const void* dout, const void* in, void* din, int64_t rows, int32_t cols,
                   int64_t dout_row_stride, int64_t in_row_stride, int64_t din_row_stride,
                   int dtype, void* stream);
+
+/* ---- timestamp / position additive encoder (the step before the STU stack) ------------------------------
+ * out[row] = alpha * x[row] + pos_w[pos_idx(row)] + ts_w[ts_idx(row)], x / out (sum L, dim) in `dtype`, tables fp32
+ * (max_pos_ind, dim) and (>= max_time_bucket + 1, dim); also writes the two int32 table indices of every row (the
+ * backward needs them).  Index arithmetic of ops/pytorch/pt_position.py:40-122 (position: bit-exact integers;
+ * time: fp32 bucket of query_time - timestamp, time_bucket_fn 0 = sqrt, 1 = log; NB the reference clamps the
+ * bucket to ts_embeddings.size(1) - 1, pass that as max_time_bucket).  timestamps (sum L) int64; num_targets may be
+ * NULL; seq_offsets / num_targets share `index_dtype`.  Replaces triton_add_timestamp_positional_embeddings
+ * (ops/triton/triton_position.py:62-158, 241-337), selected by ops/position.py:38-96. */
+int hstu_add_ts_pos_emb_fwd(const void* x, void* out, const void* seq_offsets, const int64_t* timestamps,
+                            const void* num_targets, const float* pos_w, const float* ts_w, int32_t* pos_idx,
+                            int32_t* ts_idx, int32_t batch, int32_t dim, int32_t max_contextual_seq_len,
+                            int32_t max_pos_ind, int32_t max_time_bucket, int32_t interleave_targets,
+                            int32_t time_bucket_fn, float alpha, int dtype, int index_dtype, void* stream);
+/* table_grad[i, :] = sum over e with sorted_idx[e] == i of dout[sorted_rows[e], :]  (fp32, (table_rows, dim), zeroed
+ * here): the index_select backward of one embedding table, rows pre-sorted by table index.  dim <= 1024.  Replaces
+ * _add_embeddings_bwd_kernel (ops/triton/triton_position.py:188-238, host side :339-407). */
+int hstu_embedding_grad_segment_sum(const void* dout, const int64_t* sorted_rows, const int32_t* sorted_idx, int64_t n,
+                                    int32_t dim, int32_t table_rows, float* table_grad, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -560,3 +560,63 @@ def generate_sparse_seq_len(rng: np.random.Generator, size: int, max_seq_len: in
         return rng.integers(lo, max_seq_len, size=size, dtype=np.int32)
     hi = int(2 * sparsity * max_seq_len)
     return rng.integers(0, hi, size=size, dtype=np.int32)
+
+
+# ---------------------------------------------------------------------------
+# timestamp / position additive encoder
+# reference: ops/position.py:38-96, ops/pytorch/pt_position.py:40-134, caller modules/positional_encoder.py:52-75
+# ---------------------------------------------------------------------------
+def position_indices(length, num_target, max_contextual_seq_len, max_pos_ind, interleave_targets):
+    """position-table row of every row r < length of one user (pt_position.py:40-73).  `num_target` None = no
+    targets (then index = length - r: the reference's PyTorch branch only survives full-length batches there,
+    because it also indexes the table for its padded columns)."""
+    r = np.arange(length, dtype=np.int64)
+    if num_target is not None:
+        high = length - num_target * (2 if interleave_targets else 1)
+        idx = high - np.minimum(r, high)
+    else:
+        idx = length - r
+    idx = np.minimum(idx + max_contextual_seq_len, max_pos_ind - 1)
+    if max_contextual_seq_len > 0:
+        c = min(max_contextual_seq_len, length)
+        idx[:c] = np.arange(c)
+    return idx
+
+
+def time_bucket_indices(ts_user, max_bucket, time_bucket_fn):
+    """bucket of (query time - timestamp) per row of one user (pt_position.py:100-122): fp32 arithmetic exactly as
+    torch does it -- int64 difference -> fp32, clamp(min=1e-6), / 60, sqrt | log, truncate, clamp to
+    [0, max_bucket].  NB the reference takes max_bucket = ts_embeddings.size(1) - 1 (the embedding DIM minus one,
+    `:101`), not the number of table rows; restated as is."""
+    if len(ts_user) == 0:
+        return np.zeros(0, dtype=np.int64)
+    d = (ts_user[-1] - ts_user).astype(np.float32)
+    t = np.maximum(d, np.float32(1e-6)) / np.float32(60.0)
+    t = np.log(t) if time_bucket_fn == "log" else np.sqrt(t)
+    t = np.maximum(t / np.float32(1.0), np.float32(0.0))
+    return np.clip(t.astype(np.int32).astype(np.int64), 0, max_bucket)
+
+
+def add_timestamp_positional_embeddings_fwd(alpha, x, seq_offsets, timestamps, pos_w, ts_w, max_contextual_seq_len,
+                                            num_targets, interleave_targets, time_bucket_fn):
+    """out[row] = alpha * x[row] + pos_w[pos_idx] + ts_w[ts_idx]  (ops/position.py:55, pt_position.py:123-134).
+    Returns (out, pos_idx, ts_idx) with the per-row table indices."""
+    B = len(seq_offsets) - 1
+    pos_idx = np.zeros(x.shape[0], dtype=np.int64)
+    ts_idx = np.zeros(x.shape[0], dtype=np.int64)
+    for b in range(B):
+        o, e = int(seq_offsets[b]), int(seq_offsets[b + 1])
+        nt = None if num_targets is None else int(num_targets[b])
+        pos_idx[o:e] = position_indices(e - o, nt, max_contextual_seq_len, pos_w.shape[0], interleave_targets)
+        ts_idx[o:e] = time_bucket_indices(np.asarray(timestamps[o:e], dtype=np.int64), ts_w.shape[1] - 1, time_bucket_fn)
+    out = x * alpha + (ts_w[ts_idx] + pos_w[pos_idx])
+    return out, pos_idx, ts_idx
+
+
+def add_timestamp_positional_embeddings_bwd(alpha, g, pos_idx, ts_idx, n_pos, n_ts):
+    """d x = alpha g;  d pos_w[i] = sum of g rows with pos_idx == i;  same for ts_w (index_select backward)."""
+    dpos = np.zeros((n_pos, g.shape[1]), dtype=np.float64)
+    dts = np.zeros((n_ts, g.shape[1]), dtype=np.float64)
+    np.add.at(dpos, pos_idx, g)
+    np.add.at(dts, ts_idx, g)
+    return g * alpha, dpos, dts

@@ -1,4 +1,4 @@
-"""Pure-torch stand-ins for the three fbgemm_gpu ops the reference's PyTorch path
+"""Pure-torch stand-ins for the fbgemm_gpu ops the reference's PyTorch path
 calls (fbgemm_gpu is not installed and there is no network).  Used ONLY by
 ``make_golden.py`` so the unmodified reference can run on CPU in the build
 container.  CompositeImplicitAutograd, so autograd flows through them.
@@ -14,6 +14,7 @@ _lib.define(
 )
 _lib.define("dense_to_jagged(Tensor dense, Tensor[] x_offsets, SymInt? total_L=None) -> (Tensor, Tensor[])")
 _lib.define("asynchronous_complete_cumsum(Tensor t_in) -> Tensor")
+_lib.define("jagged_dense_elementwise_add_jagged_output(Tensor x_values, Tensor[] x_offsets, Tensor y) -> (Tensor, Tensor[])")
 
 
 def _index_maps(offsets: torch.Tensor, max_len: int):
@@ -52,3 +53,14 @@ def asynchronous_complete_cumsum(t_in):
 _lib.impl("jagged_to_padded_dense", jagged_to_padded_dense, "CompositeImplicitAutograd")
 _lib.impl("dense_to_jagged", dense_to_jagged, "CompositeImplicitAutograd")
 _lib.impl("asynchronous_complete_cumsum", asynchronous_complete_cumsum, "CompositeImplicitAutograd")
+
+
+def jagged_dense_elementwise_add_jagged_output(x_values, x_offsets: List[torch.Tensor], y):
+    """x_values (sum L, D) + y[b, position in user] (B, N, D), jagged output."""
+    off = x_offsets[0]
+    B, n = y.shape[0], y.shape[1]
+    mask, _, _ = _index_maps(off, n)
+    return x_values + y.reshape((B * n,) + tuple(y.shape[2:]))[mask.view(-1)], [off]
+
+
+_lib.impl("jagged_dense_elementwise_add_jagged_output", jagged_dense_elementwise_add_jagged_output, "CompositeImplicitAutograd")

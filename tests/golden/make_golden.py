@@ -289,6 +289,41 @@ def research_case():
                 dk=_np(k.grad), dv_=_np(v.grad), dpos_w=_np(bias._pos_w.grad), dts_w=_np(bias._ts_w.grad))
 
 
+def position_cases():
+    """add_timestamp_positional_embeddings, PYTORCH branch (ops/position.py:38-96, ops/pytorch/pt_position.py:40-134):
+    the step right before the STU stack (modules/positional_encoder.py:52-75)."""
+    from generative_recommenders.ops.position import add_timestamp_positional_embeddings
+    cases = []
+    for seed, (B, N, D, ctx, targets, interleave, fn, npos, ntime) in enumerate([
+            (6, 40, 32, 0, True, False, "sqrt", 64, 48),
+            (5, 33, 16, 3, True, True, "log", 30, 48),       # position table smaller than N: index clamp
+            (4, 50, 64, 0, False, False, "sqrt", 128, 100)]):
+        gen = torch.Generator().manual_seed(100 + seed)
+        lengths = torch.randint(ctx + 4, N + 1, (B,), generator=gen)
+        lengths[0] = N
+        if not targets:   # the reference's PyTorch branch indexes the position table with L - col < 0 for padded
+            lengths[:] = N  # columns when there are no targets (IndexError): only full-length batches run there
+        nt = torch.minimum(torch.randint(1, 4, (B,), generator=gen), (lengths - ctx) // 2) if targets else None
+        offsets = torch.zeros(B + 1, dtype=torch.int64); offsets[1:] = torch.cumsum(lengths, 0)
+        Lt = int(offsets[-1])
+        ts = torch.cat([torch.sort(torch.randint(0, 3 * 10**6, (int(l),), generator=gen)).values for l in lengths])
+        x = torch.randn(Lt, D, generator=gen).requires_grad_()
+        pos_w = (0.1 * torch.randn(npos, D, generator=gen)).requires_grad_()
+        ts_w = (0.1 * torch.randn(ntime + 1, D, generator=gen)).requires_grad_()
+        alpha = float(D) ** 0.5
+        out = add_timestamp_positional_embeddings(
+            alpha=alpha, max_seq_len=N, max_contextual_seq_len=ctx, position_embeddings_weight=pos_w,
+            timestamp_embeddings_weight=ts_w, seq_offsets=offsets, seq_lengths=lengths, seq_embeddings=x,
+            timestamps=ts, num_targets=nt, interleave_targets=interleave, time_bucket_fn=fn, kernel=PT)
+        g = torch.randn_like(out)
+        out.backward(g)
+        cases.append(dict(N=N, D=D, ctx=ctx, interleave=int(interleave), fn=np.asarray(fn), alpha=alpha,
+                          offsets=_np(offsets), lengths=_np(lengths), num_targets=None if nt is None else _np(nt),
+                          ts=_np(ts), x=_np(x), pos_w=_np(pos_w), ts_w=_np(ts_w), out=_np(out), g=_np(g),
+                          dx=_np(x.grad), dpos_w=_np(pos_w.grad), dts_w=_np(ts_w.grad)))
+    return cases
+
+
 def _save_cases(path, cases):
     flat = {}
     for i, c in enumerate(cases):
@@ -311,6 +346,7 @@ def main():
     _save_cases(os.path.join(HERE, "compute.npz"), [dict(name=np.asarray(n), **c) for n, c in cc.items()])
     _save_cases(os.path.join(HERE, "stu.npz"), [stu_case()])
     _save_cases(os.path.join(HERE, "research_attention.npz"), [research_case()])
+    _save_cases(os.path.join(HERE, "position.npz"), position_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

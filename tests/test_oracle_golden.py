@@ -185,3 +185,19 @@ def test_mask_zero_history_and_properties():
     m = O.valid_attn_mask(8, 8, num_targets=2, contextual_seq_len=3)
     assert m[0, :6].all() and not m[0, 6:].any()
     assert m[7, :6].all() and m[7, 7] and not m[7, 6]
+
+
+# ------------------------------------------------------------------ §8f rank 1: timestamp / position encoder
+@pytest.mark.parametrize("idx", range(3))
+def test_oracle_matches_reference_position_encoder(idx):
+    c = load_cases("position.npz")[idx]
+    nt = c.get("num_targets")
+    out, pos_idx, ts_idx = O.add_timestamp_positional_embeddings_fwd(
+        float(c["alpha"]), c["x"].astype(np.float64), c["offsets"], c["ts"], c["pos_w"].astype(np.float64),
+        c["ts_w"].astype(np.float64), int(c["ctx"]), nt, bool(c["interleave"]), str(c["fn"]))
+    np.testing.assert_allclose(out, c["out"], rtol=1e-6, atol=1e-6)
+    dx, dpos, dts = O.add_timestamp_positional_embeddings_bwd(float(c["alpha"]), c["g"].astype(np.float64), pos_idx,
+                                                               ts_idx, c["pos_w"].shape[0], c["ts_w"].shape[0])
+    np.testing.assert_allclose(dx, c["dx"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dpos, c["dpos_w"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dts, c["dts_w"], rtol=1e-5, atol=1e-5)

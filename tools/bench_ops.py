@@ -59,6 +59,19 @@ rows = {
     "jagged_to_padded_dense": (lambda: _launch.jagged_to_padded_dense(x, off, N), L * D * es + B * N * D * es),
     "dense_to_jagged": (lambda: _launch.dense_to_jagged(dense, off, L), 2 * L * D * es),
 }
+# timestamp / position encoder (the step before the STU stack)
+from generative_recommenders_amd.ops.position import add_timestamp_positional_embeddings, _table_grad
+ts_all = torch.cat([torch.sort(torch.randint(0, 3 * 10**6, (int(l),), device=dev)).values for l in lengths.tolist()])
+pos_w = torch.randn(8192, D, device=dev) * 0.1
+ts_w = torch.randn(2049, D, device=dev) * 0.1
+nt = torch.randint(1, 21, (B,), device=dev)
+def _enc():
+    return add_timestamp_positional_embeddings(alpha=D**0.5, max_seq_len=N, max_contextual_seq_len=0, position_embeddings_weight=pos_w,
+        timestamp_embeddings_weight=ts_w, seq_offsets=off, seq_lengths=lengths, seq_embeddings=x, timestamps=ts_all, num_targets=nt,
+        interleave_targets=False)
+pidx = torch.randint(0, 200, (L,), device=dev, dtype=torch.int32)
+rows["add_timestamp_positional_embeddings fwd"] = (_enc, 2 * L * D * es + L * 8)
+rows["position-table gradient (sort + segment sum)"] = (lambda: _table_grad(dy, pidx, 8192), L * D * es + 8192 * D * 4)
 out = {"shape": {"users": B, "rows": L, "D": D, "heads": H, "dtype": "bf16"}, "peak_GBps": PEAK, "kernels": {}}
 for name, (fn, nbytes) in rows.items():
     t = timed(fn)
