@@ -84,6 +84,8 @@ SIGNATURES = {
     "hstu_silu_fwd": (_int, [_vp, _vp, _i64, _i32, _i64, _i64, _int, _vp]),
     "hstu_silu_bwd": (_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _int, _vp]),
     "hstu_add_ts_pos_emb_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _int, _int, _vp]),
+    "hstu_l2_norm_fwd": (_int, [_vp, _vp, _i64, _i32, _f32, _int, _vp]),
+    "hstu_l2_norm_bwd": (_int, [_vp, _vp, _vp, _i64, _i32, _f32, _int, _vp]),
     "hstu_embedding_grad_segment_sum": (_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _int, _vp]),
 }
 

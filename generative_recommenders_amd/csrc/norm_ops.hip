@@ -724,6 +724,56 @@ static int silu_launch(const void* dout, const void* in, void* out, int64_t rows
   return check_launch("silu");
 }
 
+// ------------------------------------------------------------------ row L2 normalisation (output postprocessor)
+// y = x / max(||x||_2, eps)   (modules/postprocessors.py:55-69: seq / linalg.norm(seq).clamp(min=1e-6)), one wave per
+// row, fp32 math.  Backward: with n = ||x||: n > eps -> dx = (g - y <y, g>) / n;  n <= eps (the clamp is active and
+// has zero gradient) -> dx = g / eps.
+template <typename T, int VEC, bool BWD>
+__global__ __launch_bounds__(kNormThreads) void l2_norm_kernel(const T* x, const T* g, T* out, int64_t rows, int dim, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
+  for (int64_t row = (int64_t)blockIdx.x * kNormWaves + wave; row < rows; row += (int64_t)gridDim.x * kNormWaves) {
+    RowVec<T, VEC> xv[max_chunks<VEC>()], gv[max_chunks<VEC>()];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      const bool ok = k < nch && c < dim;
+      load_vec<T, VEC>(xv[k], x + row * dim + c, ok);
+      if (BWD) load_vec<T, VEC>(gv[k], g + row * dim + c, ok);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { ss += xv[k].v[i] * xv[k].v[i]; if (BWD) dot += xv[k].v[i] * gv[k].v[i]; }
+    }
+    const float n = sqrtf(wave_sum(ss));
+    const bool clamped = n <= eps;
+    const float inv = 1.0f / fmaxf(n, eps);
+    float coef = 0.f;
+    if (BWD) coef = clamped ? 0.f : wave_sum(dot) * inv * inv * inv;   // <y, g> / n * (1/n) applied to x
+#pragma unroll
+    for (int k = 0; k < max_chunks<VEC>(); ++k) {
+      const int c = (k * 64 + lane) * VEC;
+      if (k < nch && c < dim) {
+        RowVec<T, VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o.v[i] = BWD ? gv[k].v[i] * inv - xv[k].v[i] * coef : xv[k].v[i] * inv;
+        store_vec<T, VEC>(o, out + row * dim + c);
+      }
+    }
+  }
+}
+
+template <typename T, bool BWD>
+static int l2_launch(const void* x, const void* g, void* out, int64_t rows, int dim, float eps, hipStream_t st) {
+  if (rows == 0) return HSTU_OK;
+  const int v = vec_for<T>(dim, x, BWD ? g : x, out);
+  if (int e = check_dim(dim, v, "l2_norm")) return e;
+  const int nb = norm_blocks(rows);
+  constexpr int VV = sizeof(T) == 2 ? 8 : 4;
+  if (v == 1) hipLaunchKernelGGL((l2_norm_kernel<T, 1, BWD>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)x, (const T*)g, (T*)out, rows, dim, eps);
+  else hipLaunchKernelGGL((l2_norm_kernel<T, VV, BWD>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)x, (const T*)g, (T*)out, rows, dim, eps);
+  return check_launch("l2_norm");
+}
+
 }  // namespace hstu
 
 using namespace hstu;
@@ -813,6 +863,23 @@ int hstu_silu_bwd(const void* dout, const void* in, void* din, int64_t rows, int
   DISPATCH_DTYPE(dtype, (silu_launch<bf16_t, true>(dout, in, din, rows, cols, dout_row_stride, in_row_stride, din_row_stride, st)),
                  (silu_launch<f16_t, true>(dout, in, din, rows, cols, dout_row_stride, in_row_stride, din_row_stride, st)),
                  (silu_launch<float, true>(dout, in, din, rows, cols, dout_row_stride, in_row_stride, din_row_stride, st)));
+}
+
+
+int hstu_l2_norm_fwd(const void* x, void* y, int64_t rows, int32_t dim, float eps, int dtype, void* stream) {
+  if (rows > 0 && (!x || !y)) return set_error(HSTU_EINVAL, "hstu_l2_norm_fwd: x and y must be non-NULL");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DTYPE(dtype, (l2_launch<bf16_t, false>(x, nullptr, y, rows, dim, eps, st)),
+                 (l2_launch<f16_t, false>(x, nullptr, y, rows, dim, eps, st)),
+                 (l2_launch<float, false>(x, nullptr, y, rows, dim, eps, st)));
+}
+
+int hstu_l2_norm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t dim, float eps, int dtype, void* stream) {
+  if (rows > 0 && (!x || !dy || !dx)) return set_error(HSTU_EINVAL, "hstu_l2_norm_bwd: dy, x and dx must be non-NULL");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DTYPE(dtype, (l2_launch<bf16_t, true>(x, dy, dx, rows, dim, eps, st)),
+                 (l2_launch<f16_t, true>(x, dy, dx, rows, dim, eps, st)),
+                 (l2_launch<float, true>(x, dy, dx, rows, dim, eps, st)));
 }
 
 }  // extern "C"

@@ -324,3 +324,25 @@ def silu_bwd(dout: torch.Tensor, x: torch.Tensor, din: Optional[torch.Tensor] = 
                                       dout.stride(0), x.stride(0), din.stride(0), L.torch_dtype_code(x.dtype),
                                       L.current_stream_ptr(x.device)))
     return din
+
+
+# ----------------------------------------------------------------------------- row L2 normalisation
+def l2_norm_fwd(x: torch.Tensor, eps: float) -> torch.Tensor:
+    L.require_gpu_tensor(x, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1] if x.numel() else 0
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_l2_norm_fwd(x.data_ptr(), y.data_ptr(), rows, x.shape[-1], float(eps), L.torch_dtype_code(x.dtype),
+                                         L.current_stream_ptr(x.device)))
+    return y
+
+
+def l2_norm_bwd(dy: torch.Tensor, x: torch.Tensor, eps: float) -> torch.Tensor:
+    dy, x = dy.contiguous(), x.contiguous()
+    dx = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1] if x.numel() else 0
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_l2_norm_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), rows, x.shape[-1], float(eps),
+                                         L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
+    return dx

@@ -239,6 +239,13 @@ int hstu_add_ts_pos_emb_fwd(const void* x, void* out, const void* seq_offsets, c
 int hstu_embedding_grad_segment_sum(const void* dout, const int64_t* sorted_rows, const int32_t* sorted_idx, int64_t n,
                                     int32_t dim, int32_t table_rows, float* table_grad, int dtype, void* stream);
 
+/* ---- output postprocessor: row L2 normalisation ---------------------------------------------------------
+ * y = x / max(||x||_2, eps) per row of (rows, dim), and its backward.  Replaces L2NormPostprocessor.forward
+ * (modules/postprocessors.py:55-69: seq / linalg.norm(seq, dim=-1).clamp(min=1e-6)) and its autograd. */
+int hstu_l2_norm_fwd(const void* x, void* y, int64_t rows, int32_t dim, float eps, int dtype, void* stream);
+int hstu_l2_norm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t dim, float eps, int dtype,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

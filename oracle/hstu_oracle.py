@@ -620,3 +620,28 @@ def add_timestamp_positional_embeddings_bwd(alpha, g, pos_idx, ts_idx, n_pos, n_
     np.add.at(dpos, pos_idx, g)
     np.add.at(dts, ts_idx, g)
     return g * alpha, dpos, dts
+
+
+# ---------------------------------------------------------------------------
+# output post-processing
+# reference: modules/postprocessors.py:55-69 (l2 norm), modules/hstu_transducer.py:191-251 (candidate split)
+# ---------------------------------------------------------------------------
+def l2_norm_fwd(x, eps=1e-6):
+    """x / max(||x||_2, eps) per row (postprocessors.py:66-68)."""
+    n = np.sqrt((x * x).sum(axis=-1, keepdims=True))
+    return x / np.maximum(n, eps)
+
+
+def l2_norm_bwd(g, x, eps=1e-6):
+    """n > eps: (g - y <y, g>) / n;  n <= eps (clamp active, zero gradient through it): g / eps."""
+    n = np.sqrt((x * x).sum(axis=-1, keepdims=True))
+    y = x / np.maximum(n, eps)
+    return np.where(n > eps, (g - y * (y * g).sum(axis=-1, keepdims=True)) / np.maximum(n, eps), g / eps)
+
+
+def split_candidates(values, lengths, num_targets):
+    """rows of the last num_targets[b] positions of every user, concatenated (hstu_transducer.py:207-221: the right
+    part of split_2D_jagged with uih lengths = lengths - num_targets).  Returns (candidates, source row indices)."""
+    off = complete_cumsum(np.asarray(lengths, dtype=np.int64))
+    idx = np.concatenate([np.arange(off[b + 1] - int(num_targets[b]), off[b + 1]) for b in range(len(lengths))]).astype(np.int64)
+    return values[idx], idx

@@ -324,6 +324,57 @@ def position_cases():
     return cases
 
 
+def postprocess_cases():
+    """Output postprocessors (modules/postprocessors.py:55-103) and HSTUTransducer._postprocess
+    (modules/hstu_transducer.py:191-251: candidate split + postprocessor), fp32."""
+    import types
+    from generative_recommenders.modules.hstu_transducer import HSTUTransducer
+    from generative_recommenders.modules.postprocessors import L2NormPostprocessor, LayerNormPostprocessor
+    gen = torch.Generator().manual_seed(77)
+    B, N, D = 6, 24, 32
+    lengths = torch.randint(3, N + 1, (B,), generator=gen)
+    nt = torch.minimum(torch.randint(1, 5, (B,), generator=gen), lengths - 1)
+    Lt = int(lengths.sum())
+    x = torch.randn(Lt, D, generator=gen)
+    x[1] = 0.0                       # a zero row: the clamp(min=1e-6) branch of the l2 norm
+    x[2] = 1e-9 * torch.randn(D, generator=gen)
+    ts = torch.randint(0, 10**6, (Lt,), generator=gen)
+    g = torch.randn(Lt, D, generator=gen)
+    out = {}
+    xl = x.clone().requires_grad_()
+    yl = L2NormPostprocessor()(xl, ts, {})
+    yl.backward(g)
+    out.update(l2_out=_np(yl), l2_dx=_np(xl.grad))
+    torch.manual_seed(5)
+    lnp = LayerNormPostprocessor(embedding_dim=D, eps=1e-5)
+    with torch.no_grad():
+        lnp._layer_norm.weight.uniform_(0.5, 1.5)
+        lnp._layer_norm.bias.uniform_(-0.5, 0.5)
+    xn = x.clone().requires_grad_()
+    yn = lnp(xn, ts, {})
+    yn.backward(g)
+    out.update(ln_w=_np(lnp._layer_norm.weight), ln_b=_np(lnp._layer_norm.bias), ln_out=_np(yn), ln_dx=_np(xn.grad),
+               ln_dw=_np(lnp._layer_norm.weight.grad), ln_db=_np(lnp._layer_norm.bias.grad))
+    # _postprocess with a stand-in self carrying exactly the attributes the method reads
+    for full in (False, True):
+        fake = types.SimpleNamespace(
+            _return_full_embeddings=full, _output_postprocessor=L2NormPostprocessor(),
+            _input_preprocessor=types.SimpleNamespace(interleave_targets=lambda: False),
+            hammer_kernel=lambda: PT)
+        xs = x.clone().requires_grad_()
+        full_emb, cand = HSTUTransducer._postprocess(
+            fake, max_seq_len=N, total_uih_len=int((lengths - nt).sum()), total_targets=int(nt.sum()), seq_lengths=lengths,
+            seq_timestamps=ts, seq_embeddings=xs, num_targets=nt, seq_payloads={})
+        gc = torch.randn(cand.shape, generator=torch.Generator().manual_seed(9))
+        cand.backward(gc)
+        tag = "full" if full else "cand"
+        out.update({f"pp_{tag}_cand": _np(cand), f"pp_{tag}_gc": _np(gc), f"pp_{tag}_dx": _np(xs.grad)})
+        if full:
+            out["pp_full_emb"] = _np(full_emb)
+    out.update(N=N, D=D, lengths=_np(lengths), num_targets=_np(nt), x=_np(x), ts=_np(ts), g=_np(g))
+    return [out]
+
+
 def _save_cases(path, cases):
     flat = {}
     for i, c in enumerate(cases):
@@ -347,6 +398,7 @@ def main():
     _save_cases(os.path.join(HERE, "stu.npz"), [stu_case()])
     _save_cases(os.path.join(HERE, "research_attention.npz"), [research_case()])
     _save_cases(os.path.join(HERE, "position.npz"), position_cases())
+    _save_cases(os.path.join(HERE, "postprocess.npz"), postprocess_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -201,3 +201,23 @@ def test_oracle_matches_reference_position_encoder(idx):
     np.testing.assert_allclose(dx, c["dx"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(dpos, c["dpos_w"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(dts, c["dts_w"], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ §8f rank 2: output post-processing
+def test_oracle_matches_reference_postprocessors():
+    c = load_cases("postprocess.npz")[0]
+    x, g = c["x"].astype(np.float64), c["g"].astype(np.float64)
+    np.testing.assert_allclose(O.l2_norm_fwd(x), c["l2_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(O.l2_norm_bwd(g, x), c["l2_dx"], rtol=2e-5, atol=1e-4)
+    y = O.layer_norm_fwd(x, c["ln_w"].astype(np.float64), c["ln_b"].astype(np.float64), 1e-5)
+    np.testing.assert_allclose(y, c["ln_out"], rtol=1e-5, atol=1e-5)
+    # candidate split + l2 norm (return_full_embeddings = False): postprocessor on the candidate rows only
+    cand, idx = O.split_candidates(x, c["lengths"], c["num_targets"])
+    np.testing.assert_allclose(O.l2_norm_fwd(cand), c["pp_cand_cand"], rtol=1e-5, atol=1e-6)
+    dx = np.zeros_like(x)
+    dx[idx] = O.l2_norm_bwd(c["pp_cand_gc"].astype(np.float64), cand)
+    np.testing.assert_allclose(dx, c["pp_cand_dx"], rtol=2e-5, atol=1e-4)
+    # return_full_embeddings = True: postprocessor on every row, then the split
+    full = O.l2_norm_fwd(x)
+    np.testing.assert_allclose(full, c["pp_full_emb"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(full[idx], c["pp_full_cand"], rtol=1e-5, atol=1e-6)

@@ -72,6 +72,8 @@ def _enc():
 pidx = torch.randint(0, 200, (L,), device=dev, dtype=torch.int32)
 rows["add_timestamp_positional_embeddings fwd"] = (_enc, 2 * L * D * es + L * 8)
 rows["position-table gradient (sort + segment sum)"] = (lambda: _table_grad(dy, pidx, 8192), L * D * es + 8192 * D * 4)
+rows["l2_norm_fwd (output postprocessor)"] = (lambda: _launch.l2_norm_fwd(x, 1e-6), 2 * L * D * es)
+rows["l2_norm_bwd"] = (lambda: _launch.l2_norm_bwd(dy, x, 1e-6), 3 * L * D * es)
 out = {"shape": {"users": B, "rows": L, "D": D, "heads": H, "dtype": "bf16"}, "peak_GBps": PEAK, "kernels": {}}
 for name, (fn, nbytes) in rows.items():
     t = timed(fn)
