@@ -348,7 +348,37 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   }
   HSTU_MARK(20);
 
-  // ---- epilogue: O^T accumulators -> out rows
+  // ---- epilogue: O^T accumulators (column n32 = query row, registers = features) -> out rows.  16-bit I/O with
+  // the instantiated head dim: through LDS (the K/V ring is dead: each wave writes its [32][DV] tile in the swizzled
+  // row-major layout, reads 16-byte units back with 16 consecutive lanes per row and stores whole rows with dwordx4);
+  // storing the accumulators directly is DV/4 dwordx2 stores per lane that touch 64 rows each (store-issue bound).
+  if constexpr (C::EB == 2 && C::SMEM >= 4 * C::VT) {
+    if (p.dv == DV) {     // wave-uniform
+      __syncthreads();    // every wave is done with the ring
+      char* tile = smem + wave * C::VT;
+      if (wave_active) {
+#pragma unroll
+        for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            u32x2 v = {E::pk2(oacc[d][4 * rq] * p.scale, oacc[d][4 * rq + 1] * p.scale),
+                       E::pk2(oacc[d][4 * rq + 2] * p.scale, oacc[d][4 * rq + 3] * p.scale)};
+            *LDS_PTR(u32x2, tile + tile_off<C::UPR_V>(n32, 4 * d + rq) + 8 * hf) = v;
+          }
+        char* obase = (char*)p.out + ((q_base + r0) * p.o_row_stride + (int64_t)hd * p.o_head_stride) * C::EB;
+        const int rows_valid = nq_rows - r0;
+#pragma unroll
+        for (int i = 0; i < 32 * C::UPR_V / 64; ++i) {
+          const int idx = i * 64 + lane;
+          const int row = idx / C::UPR_V, unit = idx % C::UPR_V;
+          const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<C::UPR_V>(row, unit));
+          if (row < rows_valid) gstore16(obase + (int64_t)row * p.o_row_stride * C::EB + unit * 16, v);
+        }
+      }
+      HSTU_MARK(21);
+      return;
+    }
+  }
   if (row_ok) {
     char* orow = (char*)p.out + ((q_base + my_row) * p.o_row_stride + (int64_t)hd * p.o_head_stride) * C::EB;
 #pragma unroll
