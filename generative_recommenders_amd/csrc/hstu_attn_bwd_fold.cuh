@@ -456,9 +456,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     HSTU_MARK(14);
     __syncthreads();   // dS' of this step published; stage reads done
     HSTU_MARK(15);
-#ifndef HSTU_FOLD_DMA_LATE
     if (k + 1 < ns) stage_dma(a - 1, bq + 1, bq + 1 < a - 1);
-#endif
     if (k > 0) {   // dk / dv of the previous step's diagonal key tile (parked in K/V slot a + 1): out, by all waves
       const int kt1 = a + 1;
       fold_copy_out<T, DQK>(smem + kt1 * C::PAIR, dk_head + (int64_t)(32 * kt1) * dk_rs, dk_rs, len - 32 * kt1, tid);
@@ -484,9 +482,6 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
         for (int r = 0; r < 16; ++r) dv_acc[d][r] = 0.f;
     }
     HSTU_MARK(23);
-#ifdef HSTU_FOLD_DMA_LATE
-    if (k + 1 < ns) stage_dma(a - 1, bq + 1, bq + 1 < a - 1);
-#endif
   }
   HSTU_MARK(20);
   // ---- tail.  Key tiles 0..nb-1 have two partial sums: side A (wave t) and side B (wave 7 - t).  Each of the two
