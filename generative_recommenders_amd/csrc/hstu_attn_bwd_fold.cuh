@@ -277,17 +277,25 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   using F = FoldCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
-  if (wave >= DQK / 16) return;
+  // Wave w owns the 32 feature columns [32 (w & 3), +32) of query rows [16 (w >> 2), +16) of BOTH tiles: two
+  // accumulators per side.  The A rows (features) of the two MFMAs are interleaved in groups of 4 -- MFMA h covers
+  // features 8 m' + 4 h + r (m' = 0..3 = the C layout's lane group, r = 0..3 = its register) -- so that a lane ends
+  // up with 8 CONSECUTIVE features of one query row: one 16-byte store per side instead of two scattered 8-byte
+  // ones (scattered 8-byte stores are store-issue bound).  The interleave costs nothing: a transposed LDS read takes
+  // its four 4-element pieces per row from arbitrary addresses.
+  const int db = wave & 3, qb = wave >> 2;
+  if (db >= DQK / 32) return;
   const int i16 = lane & 15, g = lane >> 4;
   const int row_lo = 8 * g + (i16 >> 2), row_hi = row_lo + 4;
-  const int colK = 16 * wave + 4 * (i16 & 3);
-  const int k_lo = tile_off<C::UPR_K>(row_lo, colK >> 3) + ((colK & 7) << 1);
-  const int k_hi = tile_off<C::UPR_K>(row_hi, colK >> 3) + ((colK & 7) << 1);
-  const int d0_lo = fold_ds_off(row_lo, i16 & 3), d0_hi = fold_ds_off(row_hi, i16 & 3);             // q rows 0..15
-  const int d1_lo = fold_ds_off(row_lo, 4 + (i16 & 3)), d1_hi = fold_ds_off(row_hi, 4 + (i16 & 3));   // q rows 16..31
+  const int colK0 = 32 * db + 8 * (i16 & 3), colK1 = colK0 + 4;
+  const int k0_lo = tile_off<C::UPR_K>(row_lo, colK0 >> 3) + ((colK0 & 7) << 1);
+  const int k0_hi = tile_off<C::UPR_K>(row_hi, colK0 >> 3) + ((colK0 & 7) << 1);
+  const int k1_lo = tile_off<C::UPR_K>(row_lo, colK1 >> 3) + ((colK1 & 7) << 1);
+  const int k1_hi = tile_off<C::UPR_K>(row_hi, colK1 >> 3) + ((colK1 & 7) << 1);
+  const int d_lo = fold_ds_off(row_lo, 4 * qb + (i16 & 3)), d_hi = fold_ds_off(row_hi, 4 * qb + (i16 & 3));
   // The key-tile loops are STATIC (7 slots for side A, 4 for side B -- b <= 3 -- fully unrolled, no branches): a
-  // slot without work reads whatever its LDS slot holds and gets its K^T fragment zeroed (the dS' buffers only ever hold finite
-  // values: they are cleared at kernel start).  Straight-line code is what lets hipcc keep the LDS reads of the
+  // slot without work reads whatever its LDS slot holds and gets its dS' fragment zeroed (an idle K/V slot only ever holds
+  // finite values: K rows, parked dk tiles, or the zeros the kernel starts it with).  Straight-line code is what lets hipcc keep the LDS reads of the
   // next slots in flight under the MFMAs of this one (counted lgkmcnt waits); a runtime work list makes it drain
   // lgkmcnt to 0 at every block boundary and serialises (LDS latency + MFMA) per key tile.
   // (Scalar work is not free either: without an attention window every tile on or below the diagonal is active,
@@ -305,7 +313,7 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) acc[sd][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; ++h) acc[sd][h] = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) {
@@ -314,11 +322,11 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
       const bool on = ((sd ? on_b : on_a) >> t) & 1u;
       const char* Kt = kv + t * C::PAIR;                          // all 7 slots are always allocated
       const char* ds = dsbuf + (sd ? (kBwdWaves - 1 - t) : t) * F::DSB;
-      Frag fk = tr_frag16<T>(Kt, k_lo, k_hi);
-      const Frag f0 = tr_frag16<T>(ds, d0_lo, d0_hi), f1 = tr_frag16<T>(ds, d1_lo, d1_hi);
-      fk.v = __builtin_bit_cast(typename E::vec8, on ? __builtin_bit_cast(u32x4, fk.v) : zero4);
-      acc[sd][0] = E::mma16(fk, f0, acc[sd][0]);
-      acc[sd][1] = E::mma16(fk, f1, acc[sd][1]);
+      const Frag fk0 = tr_frag16<T>(Kt, k0_lo, k0_hi), fk1 = tr_frag16<T>(Kt, k1_lo, k1_hi);
+      Frag fd = tr_frag16<T>(ds, d_lo, d_hi);
+      fd.v = __builtin_bit_cast(typename E::vec8, on ? __builtin_bit_cast(u32x4, fd.v) : zero4);
+      acc[sd][0] = E::mma16(fk0, fd, acc[sd][0]);
+      acc[sd][1] = E::mma16(fk1, fd, acc[sd][1]);
     }
   }
   // requested instruction order (hipcc would otherwise, short of registers, serialise read -> wait -> MFMA per
@@ -329,24 +337,22 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
       if (FOLD_DQ_DEPTH == 1 && sl + 1 < NSLOT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // zeroing of an idle slot's K^T fragment
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // zeroing of an idle slot's dS' fragment
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       if (FOLD_DQ_DEPTH == 2 && sl + 2 < NSLOT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
     }
   }
   HSTU_MARK(16);
-  // C layout: column i16 = query row, register r = feature 16 wave + 4 g + r
+  // C layout of MFMA h: column i16 = query row, register r = feature 32 db + 8 g + 4 h + r
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) {
     if (sd == 1 && !b_on) break;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qrow = 32 * (sd ? bq : a) + 16 * qb + i16;
-      if (qrow < mc.len) {
-        char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
-        store4<T>(dqrow, 16 * wave + 4 * g, acc[sd][qb][0] * ds_scale, acc[sd][qb][1] * ds_scale, acc[sd][qb][2] * ds_scale,
-                  acc[sd][qb][3] * ds_scale);
-      }
+    const int qrow = 32 * (sd ? bq : a) + 16 * qb + i16;
+    if (qrow < mc.len) {
+      char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
+      u32x4 v = {E::pk2(acc[sd][0][0] * ds_scale, acc[sd][0][1] * ds_scale), E::pk2(acc[sd][0][2] * ds_scale, acc[sd][0][3] * ds_scale),
+                 E::pk2(acc[sd][1][0] * ds_scale, acc[sd][1][1] * ds_scale), E::pk2(acc[sd][1][2] * ds_scale, acc[sd][1][3] * ds_scale)};
+      gstore16(dqrow + (32 * db + 8 * g) * C::EB, v);
     }
   }
 }
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   using C = BwdCfg<T, DQK, DV>;
   using F = FoldCfg<T, DQK, DV>;
   static_assert(C::EB == 2, "the folded backward is built for 16-bit I/O");
-  static_assert(DQK / 16 <= kBwdWaves, "dQ GEMM: one 16-column block per wave");
+  static_assert(DQK / 32 <= 4, "dQ GEMM: 32 feature columns x 16 query rows per wave");
   static_assert(DQK == DV, "hand-over regions assume equal K and V tile sizes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const HstuAttnParams& p = bp.fwd;
@@ -407,6 +413,10 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   }
   stage_dma(nt - 1, 0, 0 < nt - 1);
   for (int i = tid; i < kBwdWaves * F::DSB / 16; i += kBwdThreads) *LDS_PTR(u32x4, dsbuf + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+  // K tiles of slots this user does not fill: the dQ GEMM reads every slot (times a zeroed dS' fragment), so they
+  // must hold finite values
+  for (int t = nt; t < F::kMaxTiles; ++t)
+    for (int i = tid; i < C::KT / 16; i += kBwdThreads) *LDS_PTR(u32x4, smem + t * C::PAIR + 16 * i) = u32x4{0u, 0u, 0u, 0u};
   HSTU_MARK(2);
 
   f32x16 dk_acc[C::DBQ], dv_acc[C::DBV];
