@@ -428,7 +428,54 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
     float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
     for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) row[i] = hpos[i] * p.scale;
   }
-  // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv
+  // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv.  16-bit I/O with the
+  // instantiated head dims: through LDS -- each owner wave writes its two [32 keys][D] tiles over its own (dead) K/V
+  // tiles in the swizzled row-major layout, reads 16-byte units back with 16 consecutive lanes per row and stores
+  // whole rows with dwordx4 (storing the accumulators directly is D/4 scattered dwordx2 stores per lane: store-issue
+  // bound, see hstu_attn_fwd.cuh).
+  if constexpr (C::EB == 2) {
+    if (p.dqk == DQK && p.dv == DV) {   // wave-uniform
+      __syncthreads();                  // the last dQ GEMM has read every K tile
+      if (tile_owner) {
+        char* kt = smem + wave * C::PAIR;
+        char* vt = kt + C::KT;
+#pragma unroll
+        for (int d = 0; d < C::DBQ; ++d)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            u32x2 v = {E::pk2(dk_acc[d][4 * rq] * ds_scale, dk_acc[d][4 * rq + 1] * ds_scale),
+                       E::pk2(dk_acc[d][4 * rq + 2] * ds_scale, dk_acc[d][4 * rq + 3] * ds_scale)};
+            *LDS_PTR(u32x2, kt + tile_off<C::UPR_K>(n32, 4 * d + rq) + 8 * hf) = v;
+          }
+#pragma unroll
+        for (int d = 0; d < C::DBV; ++d)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            u32x2 v = {E::pk2(dv_acc[d][4 * rq] * p.scale, dv_acc[d][4 * rq + 1] * p.scale),
+                       E::pk2(dv_acc[d][4 * rq + 2] * p.scale, dv_acc[d][4 * rq + 3] * p.scale)};
+            *LDS_PTR(u32x2, vt + tile_off<C::UPR_V>(n32, 4 * d + rq) + 8 * hf) = v;
+          }
+        const int rows_valid = len - k0w;
+        char* dkt = (char*)bp.dk + ((off0 + k0w) * bp.dk_row_stride + (int64_t)hd * bp.dk_head_stride) * C::EB;
+        char* dvt = (char*)bp.dv + ((off0 + k0w) * bp.dv_row_stride + (int64_t)hd * bp.dv_head_stride) * C::EB;
+#pragma unroll
+        for (int i = 0; i < 32 * C::UPR_K / 64; ++i) {
+          const int idx = i * 64 + lane;
+          const int row = idx / C::UPR_K, unit = idx % C::UPR_K;
+          const u32x4 v = *LDS_PTR(const u32x4, kt + tile_off<C::UPR_K>(row, unit));
+          if (row < rows_valid) gstore16(dkt + (int64_t)row * bp.dk_row_stride * C::EB + unit * 16, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 32 * C::UPR_V / 64; ++i) {
+          const int idx = i * 64 + lane;
+          const int row = idx / C::UPR_V, unit = idx % C::UPR_V;
+          const u32x4 v = *LDS_PTR(const u32x4, vt + tile_off<C::UPR_V>(row, unit));
+          if (row < rows_valid) gstore16(dvt + (int64_t)row * bp.dv_row_stride * C::EB + unit * 16, v);
+        }
+      }
+      return;
+    }
+  }
   if (key_ok) {
       char* dkrow = (char*)bp.dk + ((off0 + key) * bp.dk_row_stride + (int64_t)hd * bp.dk_head_stride) * C::EB;
       char* dvrow = (char*)bp.dv + ((off0 + key) * bp.dv_row_stride + (int64_t)hd * bp.dv_head_stride) * C::EB;
