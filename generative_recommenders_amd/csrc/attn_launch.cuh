@@ -59,7 +59,9 @@ static int bwd_tiles_inst(int max_seq_len, int extra_lds) {
   using C = BwdCfg<T, DQK, DV>;
   int nw = C::max_tiles(kLdsBudget - extra_lds);
   const int need = (max_seq_len + 31) / 32;
-  if (need < nw) nw = need;
+  if (need <= nw) return need < 1 ? 1 : need;        // one key block: no dq accumulation, no scratch
+  // several key blocks: the helpers' fp32 dq partials go through a per-wave LDS scratch tile (kDqScratchBytes)
+  nw = C::max_tiles(kLdsBudget - extra_lds - kDqScratchBytes);
   return nw < 1 ? 1 : nw;
 }
 
@@ -72,7 +74,7 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   const int nkb = (p.max_seq_len + 32 * nw - 1) / (32 * nw);
   const int groups = (p.batch * p.heads + 7) / 8;
   const int nblocks = groups * 8 * nkb;
-  const int smem = C::smem_bytes(nw, hist);
+  const int smem = C::smem_bytes(nw, hist + (nkb > 1 ? kDqScratchBytes : 0));
   if (smem > kLdsBudget) return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd: max_seq_len %d needs %d bytes of LDS for the bias histograms", p.max_seq_len, smem);
   auto kern = hstu_attn_bwd_kernel<T, DQK, DV, BIAS>;
   if (smem > 64 * 1024) {
@@ -98,9 +100,9 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial);
   if (int e = check_launch("hstu_attn_bwd")) return e;
   if (nkb > 1) {
-    const int64_t n = bp.total_rows * p.heads * (int64_t)p.dqk;
+    const int64_t n = bp.total_rows * p.heads * (int64_t)(p.dqk / 8);   // 8 features per thread
     int blocks = (int)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(hstu_dq_convert_kernel<T>, dim3(blocks), dim3(256), 0, st, acc, bp.dq, bp.total_rows, p.heads,
                        p.dqk, bp.dq_row_stride, bp.dq_head_stride);
     if (int e = check_launch("hstu_attn_bwd(dq convert)")) return e;

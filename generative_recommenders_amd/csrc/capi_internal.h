@@ -33,4 +33,5 @@ int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int ex
 
 inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }
 constexpr int kLdsBudget = 160 * 1024;
+constexpr int kDqScratchBytes = 8 * 4096;   // general backward, several key blocks: one [32 q][32 d] fp32 tile per wave
 }  // namespace hstu

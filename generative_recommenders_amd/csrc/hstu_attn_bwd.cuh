@@ -91,7 +91,7 @@ HSTU_DEV typename Elem<T>::Frag dsbuf_col_frag(const char* buf, int rowA, int ro
 template <typename T, int DQK, int DV, int NB>
 HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* smem, const char* ds_base,
                             int nw, int kb0, int i0, int db0, int dstep, int64_t off0, int hd, float ds_scale,
-                            float* dq_accum, int lane) {
+                            float* dq_accum, char* dq_scratch, int lane) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -125,11 +125,11 @@ HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   }
   // C layout: column n32 = query row, register r = d within the 32-block
   const int qrow = i0 + n32;
-  if (qrow < len) {
+  if (dq_accum == nullptr && qrow < len) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const int db = db0 + n * dstep;
-      if (dq_accum == nullptr) {
+      {
         char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -138,13 +138,38 @@ HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
             store4<T>(dqrow, d0, acc[n][4 * rq] * ds_scale, acc[n][4 * rq + 1] * ds_scale, acc[n][4 * rq + 2] * ds_scale,
                       acc[n][4 * rq + 3] * ds_scale);
         }
-      } else {
-        float* arow = dq_accum + ((off0 + qrow) * p.heads + hd) * (int64_t)p.dqk;
+      }
+    }
+  }
+  if (dq_accum != nullptr) {
+    // several key blocks: fp32 partials are ADDED to the workspace.  In the C layout a lane holds one query row, so
+    // one atomic instruction would touch 64 different cache lines (measured: ~1100 cycles per instruction, a 9x
+    // cliff at the first sequence length that needs two key blocks).  Through a per-wave LDS tile instead: written
+    // in the C layout, read back with a lane = one feature column, so an instruction adds two whole 128-byte rows.
+    // (No predication: rows >= len / columns >= dqk add 0.0 to a clamped, valid address -- a masked atomic makes
+    // hipcc reload spilled addresses and drain vmcnt in front of every single one.)
+    const int hsel = lane >> 5, col = lane & 31;
+    float* const base = dq_accum + ((off0 + i0) * p.heads + hd) * (int64_t)p.dqk;   // wave-uniform
+    const int rstride = p.heads * p.dqk;
+    const int rmax = len - 1 - i0;                                                    // last real row of the tile (>= 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = 32 * db + (r & 3) + 8 * (r >> 2) + 4 * hf;
-          if (d < p.dqk) atomicAdd(arow + d, acc[n][r] * ds_scale);
-        }
+    for (int n = 0; n < NB; ++n) {
+      const int db = db0 + n * dstep;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 v4 = {acc[n][4 * rq] * ds_scale, acc[n][4 * rq + 1] * ds_scale, acc[n][4 * rq + 2] * ds_scale,
+                    acc[n][4 * rq + 3] * ds_scale};
+        *LDS_PTR(f32x4, dq_scratch + n32 * 128 + (((2 * rq + hf) ^ (n32 & 7)) << 4)) = v4;
+      }
+      const int d = 32 * db + col;
+      const bool col_ok = d < p.dqk;
+      const int dc = col_ok ? d : 0;
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int row = 2 * i + hsel;
+        float v = *LDS_PTR(const float, dq_scratch + row * 128 + ((((col >> 2) ^ (row & 7)) << 4) | ((col & 3) << 2)));
+        v = (col_ok && row <= rmax) ? v : 0.f;
+        atomicAdd(base + min(row, rmax) * rstride + dc, v);
       }
     }
   }
@@ -154,20 +179,20 @@ HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 template <typename T, int DQK, int DV>
 HSTU_DEV void bwd_dq_tile(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* smem, const char* ds_base, int nw,
                           int kb0, int i0, int rank, int n_help, int64_t off0, int hd, float ds_scale, float* dq_accum,
-                          int lane) {
+                          char* dq_scratch, int lane) {
   constexpr int DBQ = DQK / 32;
   if constexpr (DBQ >= 2) {
     if (2 * n_help <= DBQ) {   // few helpers: each takes pairs of blocks (rank, rank + n_help), ...
       for (int db = rank; db + n_help < DBQ; db += 2 * n_help)
-        bwd_dq_blocks<T, DQK, DV, 2>(bp, mc, smem, ds_base, nw, kb0, i0, db, n_help, off0, hd, ds_scale, dq_accum, lane);
+        bwd_dq_blocks<T, DQK, DV, 2>(bp, mc, smem, ds_base, nw, kb0, i0, db, n_help, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
       if ((DBQ / n_help) & 1)  // odd number of rounds: one single block left per helper
         for (int db = rank + (DBQ / n_help - 1) * n_help; db < DBQ; db += n_help)
-          bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, lane);
+          bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
       return;
     }
   }
   for (int db = rank; db < DBQ; db += n_help)
-    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, lane);
+    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
 }
 
 template <typename T, int DQK, int DV, bool BIAS = false>
@@ -196,7 +221,12 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int kb0 = kb * 32 * nw;
   if (kb0 >= len) return;
   const MaskCtx mc = make_mask_ctx(p, b, len);
-  HSTU_TRACE_DECL(bp.workspace, bp.workspace != nullptr && dq_accum == nullptr && blockIdx.x == 4096);
+#ifdef HSTU_TRACE
+  // one key block: the (otherwise unused) workspace pointer carries the trace buffer; several key blocks: the
+  // forward kernel's trace pointer (set with hstu_trace_set_fwd) is borrowed
+  HSTU_TRACE_DECL(dq_accum == nullptr ? bp.workspace : (void*)g_hstu_trace_fwd,
+                  (dq_accum == nullptr ? bp.workspace != nullptr : g_hstu_trace_fwd != nullptr) && blockIdx.x == 4096);
+#endif
   HSTU_MARK(1);
 
   char* const stage = smem + nw * C::PAIR;           // Q_i tile then dO_i tile
@@ -206,7 +236,9 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   // research-path bias: per-workgroup fp32 histograms of dS' over (j - i) and over the time bucket,
   // flushed to this workgroup's row of `bias_partial` and summed by a second kernel
   BiasCtx bc;
-  float* const hpos = (float*)(dsbuf + 2 * nw * C::DSBUF);
+  // several key blocks: a [32 q][32 d] fp32 tile per wave for the coalesced dq adds, then the bias histograms
+  char* const dq_scratch = dsbuf + 2 * nw * C::DSBUF + wave * (kDqScratchBytes / kBwdWaves);
+  float* const hpos = (float*)(dsbuf + 2 * nw * C::DSBUF + (nkb > 1 ? kDqScratchBytes : 0));
   float* const hts = hpos + (2 * p.max_seq_len - 1);
   if constexpr (BIAS) {
     bc = make_bias_ctx(p, b);
@@ -273,6 +305,11 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
     const bool active = tile_owner && mc.pair_may_be_active(i0, 32, k0w, 32);
     if (active) {
       // ------------------------------ phase 1 (owner of key tile `wave`) ------------------------------
+      // (lane id laundered per phase: LDS offsets derived from it are recomputed here instead of being hoisted
+      // out of the query-tile loop and kept alive next to the 128 accumulator registers -- see hstu_attn_bwd_fold.cuh)
+      int lane_p = lane;
+      asm volatile("" : "+v"(lane_p));
+      const int n32 = lane_p & 31, hf = lane_p >> 5;
       const char* Kw = smem + wave * C::PAIR;
       const char* Vw = Kw + C::KT;
       const char* Qs = stage;
@@ -363,7 +400,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
       for (int d = 0; d < C::DBV; ++d)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          Frag a = lds_col_frag<T, C::UPR_V>(dOs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+          Frag a = lds_col_frag<T, C::UPR_V>(dOs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane_p);
           dv_acc[d] = E::mma(a, pb[ks], dv_acc[d]);
         }
       // dK_w^T[d][key] += Q_i^T[d][q] dS'[q][key]
@@ -371,7 +408,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
       for (int d = 0; d < C::DBQ; ++d)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          Frag a = lds_col_frag<T, C::UPR_K>(Qs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
+          Frag a = lds_col_frag<T, C::UPR_K>(Qs, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane_p);
           dk_acc[d] = E::mma(a, dsb[ks], dk_acc[d]);
         }
       HSTU_MARK(13);
@@ -404,24 +441,26 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         }
       }
       const char* ds_prev = dsbuf + (((it + 1) & 1) * nw) * C::DSBUF;
-      bwd_dq_tile<T, DQK, DV>(bp, mc, smem, ds_prev, nw, kb0, i0 + 32, my_rank, n_help, off0, hd, ds_scale, dq_accum, lane);
+      int lane_h = lane;
+      asm volatile("" : "+v"(lane_h));
+      bwd_dq_tile<T, DQK, DV>(bp, mc, smem, ds_prev, nw, kb0, i0 + 32, my_rank, n_help, off0, hd, ds_scale, dq_accum, dq_scratch, lane_h);
     }
     HSTU_MARK(14);
-    __syncthreads();  // stage reads done; dS'(it) complete; dS'(it+1) consumed
+    lds_barrier();  // stage reads done; dS'(it) complete; dS'(it+1) consumed (LDS-only: the dq adds stay in flight)
     HSTU_MARK(15);
     if (more) {
       tile_lds_write<T, DQK, C::NQU, kBwdThreads>(qreg, stage, i0 - 32, len, p.dqk, tid);
       tile_lds_write<T, DV, C::NOU, kBwdThreads>(oreg, stage + C::KT, i0 - 32, len, p.dv, tid);
     }
     HSTU_MARK(16);
-    __syncthreads();  // next Q/dO tile visible
+    lds_barrier();  // next Q/dO tile visible
     HSTU_MARK(18);
   }
   HSTU_MARK(20);
   // ---- dQ of the last visited query tile: every wave is idle now
   if (it_hi > it_lo && wave < C::DBQ) {
     const char* ds_prev = dsbuf + ((it_lo & 1) * nw) * C::DSBUF;
-    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_prev, nw, kb0, it_lo << 5, wave, 1, off0, hd, ds_scale, dq_accum, lane);
+    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_prev, nw, kb0, it_lo << 5, wave, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
   }
   HSTU_MARK(21);
   if constexpr (BIAS) {
@@ -500,17 +539,28 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
     }
 }
 
-// fp32 dq accumulator (rows, H, dqk) -> dq in the I/O dtype (strided)
+// fp32 dq accumulator (rows, H, dqk) -> dq in the I/O dtype (strided).  One thread per 8 consecutive features
+// (dqk is a multiple of 8): two 16-byte loads, one 16-byte (8-byte for fp32: two) store, one division per piece.
 template <typename T>
-__global__ void hstu_dq_convert_kernel(const float* acc, void* dq, int64_t rows, int heads, int dqk, int64_t row_stride,
-                                       int64_t head_stride) {
-  const int64_t n = rows * heads * (int64_t)dqk;
+__global__ __launch_bounds__(256) void hstu_dq_convert_kernel(const float* acc, void* dq, int64_t rows, int heads, int dqk,
+                                                              int64_t row_stride, int64_t head_stride) {
+  const int pph = dqk >> 3;                 // pieces per (row, head)
+  const int ppr = heads * pph;              // pieces per row
+  const int64_t n = rows * ppr;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int d = (int)(i % dqk);
-    const int64_t rh = i / dqk;
-    const int h = (int)(rh % heads);
-    const int64_t r = rh / heads;
-    ((T*)dq)[r * row_stride + h * head_stride + d] = (T)acc[i];
+    const int64_t r = i / ppr;
+    const int rem = (int)(i - r * ppr);
+    const int h = rem / pph, c = (rem - h * pph) << 3;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(acc + i * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(acc + i * 8 + 4);
+    T* out = (T*)dq + r * row_stride + h * head_stride + c;
+    if constexpr (Elem<T>::kBytes == 2) {
+      u32x4 v = {Elem<T>::pk2(a[0], a[1]), Elem<T>::pk2(a[2], a[3]), Elem<T>::pk2(b[0], b[1]), Elem<T>::pk2(b[2], b[3])};
+      *reinterpret_cast<u32x4*>(out) = v;
+    } else {
+      *reinterpret_cast<f32x4*>(out) = a;
+      *reinterpret_cast<f32x4*>(out + 4) = b;
+    }
   }
 }
 

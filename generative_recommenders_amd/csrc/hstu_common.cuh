@@ -335,6 +335,11 @@ struct TraceCtx { unsigned long long* p; bool on; int i; };
 #define HSTU_MARK(tag)
 #endif
 
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains
+// vmcnt, i.e. waits for every outstanding global store / atomic of the wave to be acknowledged -- in a loop whose
+// iterations end with atomics (the multi-key-block backward) that is a full L2 round trip per step.
+HSTU_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // 16-byte global load / store helpers
 HSTU_DEV u32x4 gload16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 HSTU_DEV void gstore16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }

@@ -7,8 +7,10 @@ import torch
 from generative_recommenders_amd.ops import _launch
 
 dev = "cuda"
-H, d, B = 4, int(os.environ.get("HD", "128")), 8192
+H, d = 4, int(os.environ.get("HD", "128"))
+TOKENS = int(os.environ.get("TOKENS", str(8192 * 200)))   # users = TOKENS / N: constant work per launch
 for N in [int(x) for x in (sys.argv[1:] or "32 64 96 128 160 192 200 224".split())]:
+    B = max(TOKENS // N, 1)
     lengths = torch.full((B,), N, dtype=torch.int64, device=dev)
     off = torch.zeros(B + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(lengths, 0)
     L = int(off[-1])
@@ -32,5 +34,6 @@ for N in [int(x) for x in (sys.argv[1:] or "32 64 96 128 160 192 200 224".split(
     run(3); tf, tb = run(10)
     nprob = B * H / 256.0
     fb, bb = L * H * 4 * d * 2, L * H * 7 * d * 2
-    print(f"N={N:4d} fwd {tf:7.3f} ms ({tf*1e3/nprob:6.2f} us/problem/CU, {fb/tf/1e6:6.0f} GB/s)  "
+    flops = 4.0 * B * H * N * (N + 1) / 2 * d      # causal half of QK^T and PV
+    print(f"N={N:5d} users {B:6d} fwd {flops/tf/1e9:6.1f} TF/s  bwd {2.5*flops/tb/1e9:6.1f} TF/s |  fwd {tf:7.3f} ms ({tf*1e3/nprob:6.2f} us/problem/CU, {fb/tf/1e6:6.0f} GB/s)  "
           f"bwd {tb:7.3f} ms ({tb*1e3/nprob:6.2f} us/problem/CU, {bb/tb/1e6:6.0f} GB/s)", flush=True)
