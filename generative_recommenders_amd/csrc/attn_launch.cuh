@@ -100,7 +100,7 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial);
   if (int e = check_launch("hstu_attn_bwd")) return e;
   if (nkb > 1) {
-    const int64_t n = bp.total_rows * p.heads * (int64_t)(p.dqk / 8);   // 8 features per thread
+    const int64_t n = bp.total_rows * p.heads * (int64_t)(p.dqk / (16 / Elem<T>::kBytes));   // 16 bytes of dq per thread
     int blocks = (int)((n + 255) / 256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(hstu_dq_convert_kernel<T>, dim3(blocks), dim3(256), 0, st, acc, bp.dq, bp.total_rows, p.heads,

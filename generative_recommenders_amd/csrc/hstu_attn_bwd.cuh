@@ -539,27 +539,28 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
     }
 }
 
-// fp32 dq accumulator (rows, H, dqk) -> dq in the I/O dtype (strided).  One thread per 8 consecutive features
-// (dqk is a multiple of 8): two 16-byte loads, one 16-byte (8-byte for fp32: two) store, one division per piece.
+// fp32 dq accumulator (rows, H, dqk) -> dq in the I/O dtype (strided).  One thread per 16 bytes of OUTPUT: 8 features
+// for 16-bit I/O, 4 for fp32 (dqk is a multiple of that -- the boundary checks it -- but not necessarily of 8).
 template <typename T>
 __global__ __launch_bounds__(256) void hstu_dq_convert_kernel(const float* acc, void* dq, int64_t rows, int heads, int dqk,
                                                               int64_t row_stride, int64_t head_stride) {
-  const int pph = dqk >> 3;                 // pieces per (row, head)
+  constexpr int VEC = 16 / Elem<T>::kBytes;
+  const int pph = dqk / VEC;                // pieces per (row, head)
   const int ppr = heads * pph;              // pieces per row
   const int64_t n = rows * ppr;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / ppr;
     const int rem = (int)(i - r * ppr);
-    const int h = rem / pph, c = (rem - h * pph) << 3;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(acc + i * 8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(acc + i * 8 + 4);
+    const int h = rem / pph, c = (rem - h * pph) * VEC;
+    const float* src = acc + i * VEC;       // the accumulator is dense: (row, head, feature)
     T* out = (T*)dq + r * row_stride + h * head_stride + c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
     if constexpr (Elem<T>::kBytes == 2) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
       u32x4 v = {Elem<T>::pk2(a[0], a[1]), Elem<T>::pk2(a[2], a[3]), Elem<T>::pk2(b[0], b[1]), Elem<T>::pk2(b[2], b[3])};
       *reinterpret_cast<u32x4*>(out) = v;
     } else {
       *reinterpret_cast<f32x4*>(out) = a;
-      *reinterpret_cast<f32x4*>(out + 4) = b;
     }
   }
 }

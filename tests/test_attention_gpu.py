@@ -290,6 +290,22 @@ def test_long_sequences_multi_block_backward():
     _run_case(c, torch.float32)
 
 
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 50), (torch.float32, 20), (torch.float32, 100), (torch.bfloat16, 50),
+                                     (torch.bfloat16, 24), (torch.float16, 72)])
+def test_multi_block_backward_head_dims_off_the_vector_width(dtype, d):
+    """Several key blocks AND a head dim that is not a multiple of 8 (ML-1M: 50): the fp32 dq accumulator is
+    (rows, H, padded d) with padded d a multiple of 4 (fp32) / 8 (16-bit) only."""
+    rng = np.random.default_rng(d)
+    lengths = np.array([640, 0, 211, 333], dtype=np.int64)
+    off = np.zeros(5, dtype=np.int64)
+    off[1:] = np.cumsum(lengths)
+    L = int(off[-1])
+    c = dict(N=640, alpha=d**-0.5, off=off, nt=None, w=0, ctx=0, mf=0,
+             q=rng.uniform(-0.1, 0.1, (L, 2, d)), k=rng.uniform(-0.1, 0.1, (L, 2, d)),
+             v=rng.uniform(-0.1, 0.1, (L, 2, d)), dout=rng.standard_normal((L, 2, d)) * 0.1)
+    _run_case(c, dtype)
+
+
 # ------------------------------------------------------------------ error behaviour (mirrors the reference's asserts)
 def test_errors():
     q = torch.zeros(4, 2, 32, device=DEV, dtype=torch.bfloat16)

@@ -1,0 +1,186 @@
+"""BASELINE.json's five configurations as parity cases (SURVEY §8(d) "Other configs as synthetic inputs").
+
+configs[1]'s attention shape at the metric size is what bench.py measures; the others are exercised here, each
+at the shape, dtype and length distribution the survey states, against the oracle where it finishes in seconds
+and through size-independent properties where it does not (C5: N up to 8192).
+
+  C1  ML-1M     B=128 N=211 H=1  d_h=50 (and 64)  fp32   research semantics (relative bias)
+  C2  ML-20M    B=128 N=211 H=4  d_h=64           bf16   research semantics + the ops-path attention
+  C3  Books     B=128 N=61  H=4  d_h=16           bf16   long-tail lengths: randint(0,30) mixed with 5 % full
+  C4  ML-3B     N<=200      H=4  d_h=64  D=256    bf16   M-jag lengths (one rank's shard)
+  C5  HSTU-large            H=16 d_h=64  N<=8192  bf16   delta-q 256 rows, num_targets = 256, forward only
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hstu_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    import generative_recommenders_amd.ops.hstu_attention as A
+
+    return A
+
+
+def _research():
+    import generative_recommenders_amd.research.modeling.sequential.hstu as R
+
+    return R
+
+
+def _rel(got, ref):
+    got = got.detach().double().cpu().numpy().reshape(ref.shape)
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+def _offsets(lengths):
+    return O.complete_cumsum(np.asarray(lengths, dtype=np.int64))
+
+
+def _timestamps_off_bucket_boundaries(rng, B, n):
+    """Sorted int64 timestamps (B, n) such that no pair's bucket coordinate log(dt)/0.301 lies within 3e-5 of an
+    integer.  A pair ON a boundary is bucketed by the last bit of the fp32 log -- numpy, torch-CPU, torch-GPU and the
+    kernel's logf legitimately disagree there (measured: 4 of 5.7 M pairs between torch-GPU and numpy) -- and because
+    the bucket gradient is a heavily cancelling sum (|sum| ~ 1e-4 of the sum of |terms|), ONE such pair moves it by
+    0.5 %.  The check wants the arithmetic, not the coin flips."""
+    out = np.empty((B, n), dtype=np.int64)
+    low = np.tril(np.ones((n, n), dtype=bool))           # the pairs attention uses: key j <= query i
+    for b in range(B):
+        for _ in range(200):
+            row = np.sort(rng.integers(0, 10**8, size=n)).astype(np.int64)
+            ext = np.concatenate([row, row[n - 1:]])
+            dt = np.maximum(np.abs(ext[1:, None] - ext[None, :-1]), 1)
+            c = np.log(dt.astype(np.float32)) / np.float32(0.301)
+            risky = low & (dt > 1) & (np.abs(c - np.round(c)) < 1.5e-5)     # log(1) = 0 is exact everywhere
+            if not risky.any():
+                break
+        else:
+            raise AssertionError("no boundary-free timestamp row found")
+        out[b] = row
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- C1 / C2 / C3
+@pytest.mark.parametrize("name,B,n,H,d,dtype,lengths_kind", [
+    ("C1-ml1m-d50", 128, 211, 1, 50, torch.float32, "uniform"),
+    ("C1-ml1m-d64", 128, 211, 1, 64, torch.float32, "uniform"),
+    ("C2-ml20m", 128, 211, 4, 64, torch.bfloat16, "uniform"),
+    ("C3-books", 128, 61, 4, 16, torch.bfloat16, "longtail"),
+])
+def test_research_configs_rel_bias_attention(name, B, n, H, d, dtype, lengths_kind):
+    """research path (hstu.py:150-223): silu(QK^T + pos/time bias)/n, causal, over the whole batch of the config."""
+    R = _research()
+    rng = np.random.default_rng(sum(map(ord, name)))
+    if lengths_kind == "uniform":
+        lengths = rng.integers(1, n + 1, size=B)          # history uniform in [1, 200] + targets, capped at N
+    else:
+        lengths = rng.integers(0, 30, size=B)              # generate_sparse_seq_len(sparsity=0.25)-like
+        lengths[rng.random(B) < 0.05] = n                  # 5 % full-length users
+        lengths[0], lengths[1] = n, 0
+    off = _offsets(lengths)
+    Lt = int(off[-1])
+    ts = _timestamps_off_bucket_boundaries(rng, B, n)
+    mk = lambda: torch.from_numpy(rng.standard_normal((Lt, H * d)) * 0.3).to(dtype)
+    q, k, v = mk(), mk(), mk()
+    g = torch.from_numpy(rng.standard_normal((Lt, H * d))).to(dtype)
+    bias = R.RelativeBucketedTimeAndPositionBasedBias(n, 128).to(DEV)
+    with torch.no_grad():
+        bias._ts_w.normal_(0, 0.02)
+        bias._pos_w.normal_(0, 0.02)
+    pos_w, ts_w, _, _ = bias.bias_params()
+    qd, kd, vd = (t.to(DEV).requires_grad_() for t in (q, k, v))
+    out = R.hstu_rel_bias_attention(H, d, d, qd, kd, vd, torch.from_numpy(off).to(DEV), torch.from_numpy(ts).to(DEV), n, bias)
+    out.backward(g.to(DEV))
+    pw, tw = pos_w.detach().double().cpu().numpy(), ts_w.detach().double().cpu().numpy()
+    q3, k3, v3 = (t.double().numpy().reshape(Lt, H, d) for t in (q, k, v))
+    ref = O.rel_bias_attention_fwd(n, q3, k3, v3, off, ts, pw, tw)
+    rq, rk, rv, rpos, rts = O.rel_bias_attention_bwd(n, g.double().numpy().reshape(Lt, H, d), q3, k3, v3, off, ts, pw, tw)
+    tol = 1e-3 if dtype == torch.float32 else 6e-3        # relative Frobenius; bf16 output rounding alone is 1.1e-3
+    assert _rel(out, ref.reshape(Lt, -1)) < tol
+    assert _rel(qd.grad, rq.reshape(Lt, -1)) < tol
+    assert _rel(kd.grad, rk.reshape(Lt, -1)) < tol
+    assert _rel(vd.grad, rv.reshape(Lt, -1)) < tol
+    assert _rel(pos_w.grad, rpos) < (2e-3 if dtype == torch.float32 else 2e-2)
+    assert _rel(ts_w.grad, rts) < (2e-3 if dtype == torch.float32 else 2e-2)
+
+
+def test_c2_ops_path_attention_bf16():
+    """configs[1] at the ML-20M shape: hstu_mha fwd+bwd, B=128, N=211, 4 heads of 64, bf16, targets on."""
+    rng = np.random.default_rng(20)
+    B, N, H, d = 128, 211, 4, 64
+    nt = rng.integers(1, 11, size=B)
+    lengths = rng.integers(0, N - 10 + 1, size=B) + nt
+    off = _offsets(lengths)
+    L = int(off[-1])
+    rnd = lambda: torch.from_numpy(rng.uniform(-0.1, 0.1, (L, H, d))).to(torch.bfloat16)
+    q, k, v = rnd(), rnd(), rnd()
+    g = torch.from_numpy(rng.standard_normal((L, H, d)) * 0.1).to(torch.bfloat16)
+    qd, kd, vd = (t.to(DEV).requires_grad_() for t in (q, k, v))
+    out = _ops().hstu_mha(N, d**-0.5, qd, kd, vd, torch.from_numpy(off).to(DEV), num_targets=torch.from_numpy(nt).to(DEV))
+    out.backward(g.to(DEV))
+    f = lambda t: t.double().numpy()
+    ref = O.hstu_mha_fwd(N, d**-0.5, f(q), f(k), f(v), off, num_targets=nt)
+    rq, rk, rv = O.hstu_mha_bwd(N, d**-0.5, f(g), f(q), f(k), f(v), off, num_targets=nt)
+    for got, want, what in ((out, ref, "out"), (qd.grad, rq, "dq"), (kd.grad, rk, "dk"), (vd.grad, rv, "dv")):
+        assert _rel(got, want) < 4e-3, what
+
+
+# ---------------------------------------------------------------------------------------------- C4
+def test_c4_one_rank_shard_of_the_dp8_batch():
+    """One rank's users of the 8192-user batch (M-jag lengths, 4 heads of 64, bf16): the oracle on the first users,
+    and the whole shard through batch-composition invariance (bit-exact: a user's rows do not depend on the batch)."""
+    rng = np.random.default_rng(1001)
+    B, N, H, d = 1024, 200, 4, 64
+    lengths = O.generate_sparse_seq_len(rng, B, N, 0.95)
+    off = _offsets(lengths)
+    L = int(off[-1])
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    qkv = torch.empty(L, H, 3 * d, device=DEV, dtype=torch.bfloat16).uniform_(-0.1, 0.1, generator=gen)
+    q, k, v = (t.detach().requires_grad_() for t in qkv.split(d, dim=-1))      # strided views of one buffer
+    g = torch.randn(L, H, d, device=DEV, dtype=torch.bfloat16, generator=gen) * 0.1
+    offt = torch.from_numpy(off).to(DEV)
+    out = _ops().hstu_mha(N, d**-0.5, q, k, v, offt)
+    out.backward(g)
+    nb = 24                                                # the oracle's share
+    Lb = int(off[nb])
+    f = lambda t: t[:Lb].detach().double().cpu().numpy()
+    ref = O.hstu_mha_fwd(N, d**-0.5, f(q), f(k), f(v), off[: nb + 1])
+    rq, rk, rv = O.hstu_mha_bwd(N, d**-0.5, f(g), f(q), f(k), f(v), off[: nb + 1])
+    for got, want, what in ((out[:Lb], ref, "out"), (q.grad[:Lb], rq, "dq"), (k.grad[:Lb], rk, "dk"), (v.grad[:Lb], rv, "dv")):
+        assert _rel(got, want) < 4e-3, what
+    # the rest of the shard: the same users in a different batch give the same bits
+    lo, hi = 700, 900
+    s, e = int(off[lo]), int(off[hi])
+    q2, k2, v2 = (t[s:e].detach().clone().requires_grad_() for t in (q, k, v))
+    out2 = _ops().hstu_mha(N, d**-0.5, q2, k2, v2, offt[lo: hi + 1] - offt[lo])
+    out2.backward(g[s:e])
+    assert torch.equal(out2, out[s:e])
+    assert torch.equal(q2.grad, q.grad[s:e]) and torch.equal(k2.grad, k.grad[s:e]) and torch.equal(v2.grad, v.grad[s:e])
+
+
+# ---------------------------------------------------------------------------------------------- C5
+def test_c5_delta_q_microbatch_long_history():
+    """M-FALCON scoring step: 256 candidate rows per user against a history of up to 8192 rows, 16 heads of 64,
+    num_targets = 256 (hstu_attention_bench.py:204-207).  Oracle on the delta rows (cheap: 256 x L per head); the
+    full forward at the same size through 'delta == tail of full' (hstu_attention_test.py:356-486), bit-exact."""
+    rng = np.random.default_rng(5)
+    B, N, H, d, delta = 3, 8192, 16, 64, 256
+    lengths = np.array([8192, 7783, 4100], dtype=np.int64)    # sparsity 0.95-like: close to N, one shorter user
+    off = _offsets(lengths)
+    L = int(off[-1])
+    gen = torch.Generator(device=DEV).manual_seed(55)
+    q, k, v = (torch.empty(L, H, d, device=DEV, dtype=torch.bfloat16).uniform_(-0.1, 0.1, generator=gen) for _ in range(3))
+    nt = torch.full((B,), delta, dtype=torch.int64, device=DEV)
+    offt = torch.from_numpy(off).to(DEV)
+    idx = torch.cat([torch.arange(off[b + 1] - delta, off[b + 1]) for b in range(B)]).to(DEV)
+    dq = q[idx].contiguous()
+    dl = _ops().delta_hstu_mha(N, d**-0.5, dq, k, v, offt, num_targets=nt)
+    f = lambda t: t.double().cpu().numpy()
+    ref = O.delta_hstu_mha_fwd(N, d**-0.5, f(dq), f(k), f(v), off, num_targets=np.full(B, delta, dtype=np.int64))
+    assert _rel(dl, ref) < 4e-3
+    full = _ops().hstu_mha(N, d**-0.5, q, k, v, offt, num_targets=nt)
+    assert torch.equal(dl, full[idx])
