@@ -151,6 +151,28 @@ def test_sweep_vs_oracle(cfg):
     _run_case(c, cfg["dtype"])
 
 
+LONG_SWEEP = []
+_r2 = np.random.default_rng(77)
+for _i in range(18):
+    LONG_SWEEP.append(dict(
+        B=int(_r2.integers(2, 5)), H=int(_r2.integers(1, 4)), max_uih=int(_r2.choice([300, 520, 900, 1400])),
+        dqk=int(_r2.choice([16, 24, 50, 64, 100, 128])), dv=int(_r2.choice([16, 40, 64, 72, 128])),
+        targets=bool(_r2.integers(0, 2)), window=bool(_r2.integers(0, 2)), ctx=int(_r2.choice([0, 0, 7])),
+        dtype=[torch.bfloat16, torch.float32, torch.float16][_i % 3], seed=_i,
+    ))
+
+
+@pytest.mark.parametrize("cfg", LONG_SWEEP, ids=lambda c: f"l{c['seed']}-{str(c['dtype'])[6:]}-q{c['dqk']}v{c['dv']}-u{c['max_uih']}")
+def test_long_sweep_vs_oracle(cfg):
+    """Several key blocks per user (fp32 dq accumulation + convert), head dims off the vector width and dqk != dv,
+    every mask variant: the general kernels away from the metric shape."""
+    rng = np.random.default_rng(5000 + cfg["seed"])
+    c = _make_case(rng, cfg["B"], cfg["H"], cfg["max_uih"], 20, cfg["dqk"], cfg["dv"], cfg["targets"], cfg["window"],
+                   cfg["ctx"], min_full=(13 if cfg["window"] and cfg["seed"] % 2 else 0),
+                   offsets_dtype=np.int32 if cfg["seed"] % 2 else np.int64)
+    _run_case(c, cfg["dtype"])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_min_full_attn_and_contextual(dtype):
     rng = np.random.default_rng(7)
