@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
           const int idx = i * 64 + lane;
           const int row = idx / C::UPR_V, unit = idx % C::UPR_V;
           const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<C::UPR_V>(row, unit));
-          if (row < rows_valid) gstore16(obase + (int64_t)row * p.o_row_stride * C::EB + unit * 16, v);
+          if (row < rows_valid) gstore16_nt(obase + (int64_t)row * p.o_row_stride * C::EB + unit * 16, v);
         }
       }
       HSTU_MARK(21);

@@ -343,5 +343,8 @@ HSTU_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 // 16-byte global load / store helpers
 HSTU_DEV u32x4 gload16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 HSTU_DEV void gstore16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+// streaming variant (written once, not read again by this kernel).  Measured: forward 1.40 -> 1.38 ms; the folded
+// backward gets SLOWER with it (3.08 -> 3.15 ms), so only the forward's output rows use it.
+HSTU_DEV void gstore16_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
 
 }  // namespace hstu
