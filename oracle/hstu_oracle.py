@@ -645,3 +645,85 @@ def split_candidates(values, lengths, num_targets):
     off = complete_cumsum(np.asarray(lengths, dtype=np.int64))
     idx = np.concatenate([np.arange(off[b + 1] - int(num_targets[b]), off[b + 1]) for b in range(len(lengths))]).astype(np.int64)
     return values[idx], idx
+
+
+# ---------------------------------------------------------------------------
+# sampled-softmax loss with a dot-product similarity
+# reference: research/modeling/sequential/losses/sampled_softmax.py:44-95 (jagged_forward),
+#            autoregressive_losses.py:37-45 (_maybe_l2_norm), :112-131 (LocalNegativesSampler.forward),
+#            rails/similarities/dot_product_similarity_fn.py:38-62
+# ---------------------------------------------------------------------------
+
+def _l2_normalize_rows(x, eps):
+    """x / clamp(||x||_2, min=eps) per row (autoregressive_losses.py:40-44)."""
+    nrm = np.sqrt((x * x).sum(axis=-1, keepdims=True))
+    return x / np.maximum(nrm, eps), nrm
+
+
+def _l2_normalize_rows_bwd(dy, x, eps):
+    """Gradient of _l2_normalize_rows: the clamp passes no gradient to the norm where ||x|| < eps."""
+    y, nrm = _l2_normalize_rows(x, eps)
+    c = np.maximum(nrm, eps)
+    proj = (y * dy).sum(axis=-1, keepdims=True)
+    return np.where(nrm >= eps, (dy - y * proj) / c, dy / c)
+
+
+def sampled_softmax_fwd(q, pos_emb, pos_ids, neg_rows, neg_ids, table, weights, temperature, l2_norm, eps=1e-6,
+                        dtype=np.float64, table_l2_norm=None):
+    """loss = sum_i w_i * (-log_softmax([l_i0, l_i1..l_iR])[0]) / sum_i w_i with
+    l_i0 = <q_i, norm(pos_emb_i)> / T,  l_ik = <q_i, norm(table[neg_rows_ik])> / T, and l_ik = -5e4 where
+    neg_ids_ik == pos_ids_i (sampled_softmax.py:60-93).  ``neg_rows`` index ``table``; ``neg_ids`` are the item ids
+    of those rows (identical for the local sampler, cached ids for the in-batch one).
+    Returns (loss, per-row loss, per-row logsumexp)."""
+    q, pos_emb, table = q.astype(dtype), pos_emb.astype(dtype), table.astype(dtype)
+    n, R = neg_rows.shape
+    tl2 = l2_norm if table_l2_norm is None else table_l2_norm    # in-batch sampler: the table is already normalised
+    pos_hat = _l2_normalize_rows(pos_emb, eps)[0] if l2_norm else pos_emb
+    row_loss = np.zeros(n, dtype=dtype)
+    lse = np.zeros(n, dtype=dtype)
+    for i in range(n):
+        neg = table[neg_rows[i]]
+        neg_hat = _l2_normalize_rows(neg, eps)[0] if tl2 else neg
+        logits = np.empty(R + 1, dtype=dtype)
+        logits[0] = (q[i] * pos_hat[i]).sum() / temperature
+        logits[1:] = np.where(neg_ids[i] == pos_ids[i], -5e4, neg_hat @ q[i] / temperature)
+        m = logits.max()
+        lse[i] = m + np.log(np.exp(logits - m).sum())
+        row_loss[i] = lse[i] - logits[0]
+    w = weights.astype(dtype)
+    return (row_loss * w).sum() / w.sum(), row_loss, lse
+
+
+def sampled_softmax_bwd(q, pos_emb, pos_ids, neg_rows, neg_ids, table, weights, temperature, l2_norm, eps=1e-6,
+                        dtype=np.float64, table_l2_norm=None):
+    """Hand-derived gradients of sampled_softmax_fwd's scalar loss w.r.t. q, pos_emb and table
+    (d loss / d l_i0 = g_i (p_i0 - 1), d loss / d l_ik = g_i p_ik for unmasked k, g_i = w_i / sum w)."""
+    q, pos_emb, table = q.astype(dtype), pos_emb.astype(dtype), table.astype(dtype)
+    n, R = neg_rows.shape
+    tl2 = l2_norm if table_l2_norm is None else table_l2_norm
+    w = weights.astype(dtype)
+    g = w / w.sum()
+    pos_hat = _l2_normalize_rows(pos_emb, eps)[0] if l2_norm else pos_emb
+    dq = np.zeros_like(q)
+    dpos_hat = np.zeros_like(pos_emb)
+    dtable = np.zeros_like(table)
+    for i in range(n):
+        neg = table[neg_rows[i]]
+        neg_hat = _l2_normalize_rows(neg, eps)[0] if tl2 else neg
+        masked = neg_ids[i] == pos_ids[i]
+        logits = np.empty(R + 1, dtype=dtype)
+        logits[0] = (q[i] * pos_hat[i]).sum() / temperature
+        logits[1:] = np.where(masked, -5e4, neg_hat @ q[i] / temperature)
+        m = logits.max()
+        p = np.exp(logits - m)
+        p /= p.sum()
+        dl = g[i] * p
+        dl[0] -= g[i]
+        dl[1:][masked] = 0.0                       # torch.where picks the constant: no gradient to the similarity
+        dq[i] = (dl[0] * pos_hat[i] + dl[1:] @ neg_hat) / temperature
+        dpos_hat[i] = dl[0] * q[i] / temperature
+        dneg_hat = dl[1:, None] * q[i][None, :] / temperature
+        dneg = _l2_normalize_rows_bwd(dneg_hat, neg, eps) if tl2 else dneg_hat
+        np.add.at(dtable, neg_rows[i], dneg)
+    dpos = _l2_normalize_rows_bwd(dpos_hat, pos_emb, eps) if l2_norm else dpos_hat
+    return dq, dpos, dtable

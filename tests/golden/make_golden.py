@@ -375,6 +375,101 @@ def postprocess_cases():
     return [out]
 
 
+def sampled_softmax_cases():
+    """SampledSoftmaxLoss (research/modeling/sequential/losses/sampled_softmax.py:44-193) with the dot-product
+    similarity (rails/similarities/dot_product_similarity_fn.py) and both negatives samplers
+    (autoregressive_losses.py:73-204), fp32.  The sampler's draw is recovered by re-seeding: its randint is the first
+    RNG use inside jagged_forward."""
+    import types
+    from generative_recommenders.research.modeling.sequential.autoregressive_losses import (
+        InBatchNegativesSampler, LocalNegativesSampler)
+    from generative_recommenders.research.modeling.sequential.losses.sampled_softmax import SampledSoftmaxLoss
+    from generative_recommenders.research.rails.similarities.dot_product_similarity_fn import DotProductSimilarity
+
+    dp = DotProductSimilarity()
+    model = types.SimpleNamespace(similarity_fn=lambda query_embeddings, item_ids, item_embeddings=None, **kw: dp(
+        query_embeddings=query_embeddings, item_embeddings=item_embeddings, item_ids=item_ids, **kw))
+    cases = []
+    # ---- local sampler (the Amazon-Books configuration: l2 norm, T = 0.05) and without norm / temperature
+    for ci, (l2, T, D, V, R, n_rows) in enumerate([(True, 0.05, 16, 40, 12, 20), (False, 1.0, 24, 15, 7, 11),
+                                                   (True, 0.05, 64, 300, 512, 9)]):
+        gen = torch.Generator().manual_seed(100 + ci)
+        all_ids = (torch.randperm(5 * V, generator=gen)[:V] + 1).tolist()       # sparse id space, 0 = padding
+        emb = torch.nn.Embedding(5 * V + 1, D)
+        with torch.no_grad():
+            emb.weight.copy_(torch.randn(5 * V + 1, D, generator=gen) * 0.5)
+            emb.weight[all_ids[0]] = 0.0                                        # a zero row: the clamp branch
+        sampler = LocalNegativesSampler(num_items=V, item_emb=emb, all_item_ids=all_ids, l2_norm=l2, l2_norm_eps=1e-6)
+        loss_mod = SampledSoftmaxLoss(num_to_sample=R, softmax_temperature=T, model=model)
+        pos_ids = torch.tensor(all_ids)[torch.randint(0, V, (n_rows,), generator=gen)]
+        q = (torch.randn(n_rows, D, generator=gen) * 0.7).requires_grad_()
+        pos_emb = emb(pos_ids).detach().clone().requires_grad_()
+        w = (torch.rand(n_rows, generator=gen) > 0.25).float()
+        seed = 4242 + ci
+        torch.manual_seed(seed)
+        loss, _ = loss_mod.jagged_forward(output_embeddings=q, supervision_ids=pos_ids, supervision_embeddings=pos_emb,
+                                          supervision_weights=w, negatives_sampler=sampler)
+        loss.backward()
+        torch.manual_seed(seed)
+        sampled_ids, _ = sampler(positive_ids=pos_ids, num_to_sample=R)
+        cases.append(dict(kind=np.asarray("local"), l2=int(l2), T=T, R=R, eps=1e-6, all_item_ids=np.asarray(all_ids),
+                          table=_np(emb.weight), q=_np(q), pos_emb=_np(pos_emb), pos_ids=_np(pos_ids), weights=_np(w),
+                          sampled_ids=_np(sampled_ids), n_collisions=int((sampled_ids == pos_ids[:, None]).sum()),
+                          loss=_np(loss), dq=_np(q.grad), dpos_emb=_np(pos_emb.grad), dtable=_np(emb.weight.grad)))
+    # ---- in-batch sampler with de-duplication
+    gen = torch.Generator().manual_seed(321)
+    B, N, D, R = 5, 9, 16, 10
+    ids = torch.randint(1, 14, (B, N), generator=gen)
+    presences = torch.rand(B, N, generator=gen) > 0.2
+    embs = (torch.randn(B, N, D, generator=gen) * 0.5).requires_grad_()
+    sampler = InBatchNegativesSampler(l2_norm=True, l2_norm_eps=1e-6, dedup_embeddings=True)
+    sampler.process_batch(ids=ids, presences=presences, embeddings=embs)
+    n_rows = 13
+    pos_ids = ids[presences][:n_rows].clone()
+    q = (torch.randn(n_rows, D, generator=gen) * 0.7).requires_grad_()
+    pos_emb = (torch.randn(n_rows, D, generator=gen) * 0.5).requires_grad_()
+    w = torch.ones(n_rows)
+    loss_mod = SampledSoftmaxLoss(num_to_sample=R, softmax_temperature=0.05, model=model)
+    torch.manual_seed(99)
+    loss, _ = loss_mod.jagged_forward(output_embeddings=q, supervision_ids=pos_ids, supervision_embeddings=pos_emb,
+                                      supervision_weights=w, negatives_sampler=sampler)
+    loss.backward()
+    torch.manual_seed(99)
+    X = sampler._cached_ids.size(0)
+    offsets = torch.randint(low=0, high=X, size=(n_rows, R), dtype=pos_ids.dtype)
+    cases.append(dict(kind=np.asarray("in-batch"), l2=1, T=0.05, R=R, eps=1e-6, ids=_np(ids), presences=_np(presences),
+                      embeddings=_np(embs), cached_ids=_np(sampler._cached_ids), cached_embeddings=_np(sampler._cached_embeddings),
+                      sampled_offsets=_np(offsets), q=_np(q), pos_emb=_np(pos_emb), pos_ids=_np(pos_ids), weights=_np(w),
+                      loss=_np(loss), dq=_np(q.grad), dpos_emb=_np(pos_emb.grad), dembeddings=_np(embs.grad)))
+    # ---- the padded entry point forward(lengths, (B, N, D) ...) -> dense_to_jagged -> jagged_forward
+    gen = torch.Generator().manual_seed(555)
+    B, N, D, V, R = 4, 7, 16, 30, 6
+    all_ids = list(range(1, V + 1))
+    emb = torch.nn.Embedding(V + 1, D)
+    with torch.no_grad():
+        emb.weight.copy_(torch.randn(V + 1, D, generator=gen) * 0.5)
+    sampler = LocalNegativesSampler(num_items=V, item_emb=emb, all_item_ids=all_ids, l2_norm=True, l2_norm_eps=1e-6)
+    lengths = torch.tensor([7, 0, 3, 5])
+    sup_ids = torch.randint(1, V + 1, (B, N), generator=gen)
+    out_emb = (torch.randn(B, N, D, generator=gen) * 0.7).requires_grad_()
+    sup_emb = emb(sup_ids).detach().clone().requires_grad_()
+    sw = torch.rand(B, N, generator=gen)
+    loss_mod = SampledSoftmaxLoss(num_to_sample=R, softmax_temperature=0.05, model=model)
+    torch.manual_seed(7)
+    loss, _ = loss_mod(lengths=lengths, output_embeddings=out_emb, supervision_ids=sup_ids, supervision_embeddings=sup_emb,
+                       supervision_weights=sw, negatives_sampler=sampler)
+    loss.backward()
+    off = torch.ops.fbgemm.asynchronous_complete_cumsum(lengths)
+    jag_ids = torch.ops.fbgemm.dense_to_jagged(sup_ids.unsqueeze(-1).float(), [off])[0].squeeze(1).long()
+    torch.manual_seed(7)
+    sampled_ids, _ = sampler(positive_ids=jag_ids, num_to_sample=R)
+    cases.append(dict(kind=np.asarray("local-padded"), l2=1, T=0.05, R=R, eps=1e-6, all_item_ids=np.asarray(all_ids),
+                      table=_np(emb.weight), lengths=_np(lengths), sup_ids=_np(sup_ids), out_emb=_np(out_emb),
+                      sup_emb=_np(sup_emb), sup_weights=_np(sw), sampled_ids=_np(sampled_ids), loss=_np(loss),
+                      dout_emb=_np(out_emb.grad), dsup_emb=_np(sup_emb.grad), dtable=_np(emb.weight.grad)))
+    return cases
+
+
 def _save_cases(path, cases):
     flat = {}
     for i, c in enumerate(cases):
@@ -399,6 +494,7 @@ def main():
     _save_cases(os.path.join(HERE, "research_attention.npz"), [research_case()])
     _save_cases(os.path.join(HERE, "position.npz"), position_cases())
     _save_cases(os.path.join(HERE, "postprocess.npz"), postprocess_cases())
+    _save_cases(os.path.join(HERE, "sampled_softmax.npz"), sampled_softmax_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

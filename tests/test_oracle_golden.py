@@ -221,3 +221,51 @@ def test_oracle_matches_reference_postprocessors():
     full = O.l2_norm_fwd(x)
     np.testing.assert_allclose(full, c["pp_full_emb"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(full[idx], c["pp_full_cand"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ §8f rank 3: sampled-softmax loss
+def _ss_inputs(c):
+    """(q, pos_emb, pos_ids, neg_rows, neg_ids, table, weights) of a golden sampled-softmax case."""
+    kind = str(c["kind"])
+    if kind == "local":
+        return c["q"], c["pos_emb"], c["pos_ids"], c["sampled_ids"], c["sampled_ids"], c["table"], c["weights"]
+    if kind == "in-batch":
+        return (c["q"], c["pos_emb"], c["pos_ids"], c["sampled_offsets"], c["cached_ids"][c["sampled_offsets"]],
+                c["cached_embeddings"], c["weights"])
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_oracle_matches_reference_sampled_softmax(idx):
+    c = load_cases("sampled_softmax.npz")[idx]
+    q, pos_emb, pos_ids, rows, ids, table, w = _ss_inputs(c)
+    kind = str(c["kind"])
+    # the in-batch sampler caches NORMALISED embeddings: the table is used as is
+    l2_table = bool(c["l2"]) and kind == "local"
+    T = float(c["T"])
+    if kind == "local":
+        assert int(c["n_collisions"]) > 0 or idx == 2     # the -5e4 branch is exercised
+    loss, _, _ = O.sampled_softmax_fwd(q, pos_emb, pos_ids, rows, ids, table, w, T, bool(c["l2"]), table_l2_norm=l2_table)
+    np.testing.assert_allclose(loss, c["loss"], rtol=2e-5)
+    dq, dpos, dtable = O.sampled_softmax_bwd(q, pos_emb, pos_ids, rows, ids, table, w, T, bool(c["l2"]), table_l2_norm=l2_table)
+    np.testing.assert_allclose(dq, c["dq"], rtol=2e-4, atol=1e-5)       # fp32 reference, 513-term sums at T = 0.05
+    np.testing.assert_allclose(dpos, c["dpos_emb"], rtol=2e-4, atol=2e-6)
+    if kind == "local":
+        np.testing.assert_allclose(dtable, c["dtable"], rtol=2e-4, atol=2e-6)
+
+
+def test_oracle_matches_reference_sampled_softmax_padded_entry():
+    """forward(lengths, (B, N, D) ...) == jagged_forward on the dense_to_jagged rows (sampled_softmax.py:97-193)."""
+    c = load_cases("sampled_softmax.npz")[4]
+    off = O.complete_cumsum(c["lengths"])
+    jag = lambda x: O.dense_to_jagged(x, off)
+    q, pe = jag(c["out_emb"].astype(np.float64)), jag(c["sup_emb"].astype(np.float64))
+    ids = jag(c["sup_ids"][..., None].astype(np.float64))[:, 0].astype(np.int64)
+    w = jag(c["sup_weights"][..., None].astype(np.float64))[:, 0]
+    loss, _, _ = O.sampled_softmax_fwd(q, pe, ids, c["sampled_ids"], c["sampled_ids"], c["table"], w, float(c["T"]), True)
+    np.testing.assert_allclose(loss, c["loss"], rtol=2e-5)
+    dq, dpos, dtable = O.sampled_softmax_bwd(q, pe, ids, c["sampled_ids"], c["sampled_ids"], c["table"], w, float(c["T"]), True)
+    np.testing.assert_allclose(dtable, c["dtable"], rtol=2e-4, atol=2e-6)
+    B, N, D = c["out_emb"].shape
+    np.testing.assert_allclose(O.jagged_to_padded_dense(dq, off, N), c["dout_emb"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(O.jagged_to_padded_dense(dpos, off, N), c["dsup_emb"], rtol=2e-4, atol=2e-6)
