@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime ou
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSTU_HIP_LIBRARY overrides the in-tree build (A/B measurements of kernel variants, packaged installs)
 LIB_PATH = os.environ.get("HSTU_HIP_LIBRARY") or os.path.join(_HERE, "libhstu_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
 HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
@@ -87,6 +87,10 @@ SIGNATURES = {
     "hstu_l2_norm_fwd": (_int, [_vp, _vp, _i64, _i32, _f32, _int, _vp]),
     "hstu_l2_norm_bwd": (_int, [_vp, _vp, _vp, _i64, _i32, _f32, _int, _vp]),
     "hstu_embedding_grad_segment_sum": (_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _int, _vp]),
+    "hstu_sampled_softmax_fwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _i32,
+                                        _i32, _f32, _vp, _vp, _int, _vp]),
+    "hstu_sampled_softmax_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _i32,
+                                        _i32, _f32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _int, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

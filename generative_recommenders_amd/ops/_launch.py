@@ -346,3 +346,50 @@ def l2_norm_bwd(dy: torch.Tensor, x: torch.Tensor, eps: float) -> torch.Tensor:
         L.check(L.lib().hstu_l2_norm_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), rows, x.shape[-1], float(eps),
                                          L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
     return dx
+
+
+# ----------------------------------------------------------------------------- sampled-softmax loss
+def _ss_rows(t: torch.Tensor, name: str) -> torch.Tensor:
+    L.require_gpu_tensor(t, name)
+    if t.dim() != 2:
+        raise RuntimeError(f"{name} must be 2-D, got {tuple(t.shape)}")
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+def sampled_softmax_fwd(q, pos_emb, pos_ids, neg_rows, neg_ids, table, temperature, pos_l2_norm, table_l2_norm, eps):
+    """-> (row_loss, lse), fp32 (n_rows)."""
+    q, pos_emb, table = _ss_rows(q, "output_embeddings"), _ss_rows(pos_emb, "supervision_embeddings"), _ss_rows(table, "table")
+    if not (q.dtype == pos_emb.dtype == table.dtype):
+        raise RuntimeError(f"embeddings must share one dtype, got {q.dtype}, {pos_emb.dtype}, {table.dtype}")
+    n, D = q.shape
+    neg_rows, neg_ids, pos_ids = neg_rows.contiguous(), neg_ids.contiguous(), pos_ids.contiguous()
+    if neg_rows.dtype != torch.int64 or neg_ids.dtype != torch.int64 or pos_ids.dtype != torch.int64:
+        raise RuntimeError("ids must be int64")
+    if neg_rows.shape != neg_ids.shape or neg_rows.dim() != 2 or neg_rows.shape[0] != n or pos_ids.shape != (n,):
+        raise RuntimeError("sampled ids must be (rows, num_negatives), supervision ids (rows,)")
+    row_loss = torch.empty(n, dtype=torch.float32, device=q.device)
+    lse = torch.empty_like(row_loss)
+    with torch.cuda.device(q.device):
+        L.check(L.lib().hstu_sampled_softmax_fwd(
+            q.data_ptr(), q.stride(0), pos_emb.data_ptr(), pos_emb.stride(0), pos_ids.data_ptr(), neg_rows.data_ptr(),
+            neg_ids.data_ptr(), table.data_ptr(), table.stride(0), table.shape[0], n, neg_rows.shape[1], D, float(temperature),
+            int(pos_l2_norm), int(table_l2_norm), float(eps), row_loss.data_ptr(), lse.data_ptr(), L.torch_dtype_code(q.dtype),
+            L.current_stream_ptr(q.device)))
+    return row_loss, lse
+
+
+def sampled_softmax_bwd(g_row, lse, q, pos_emb, pos_ids, neg_rows, neg_ids, table, temperature, pos_l2_norm, table_l2_norm, eps):
+    """-> (dq, dpos_emb) in the embedding dtype, dtable fp32 (table_rows, dim)."""
+    q, pos_emb, table = _ss_rows(q, "output_embeddings"), _ss_rows(pos_emb, "supervision_embeddings"), _ss_rows(table, "table")
+    n, D = q.shape
+    neg_rows, neg_ids, pos_ids = neg_rows.contiguous(), neg_ids.contiguous(), pos_ids.contiguous()
+    g_row = g_row.to(torch.float32).contiguous()
+    dq, dpos = torch.empty_like(q), torch.empty_like(pos_emb)
+    dtable = torch.zeros(table.shape[0], D, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        L.check(L.lib().hstu_sampled_softmax_bwd(
+            q.data_ptr(), q.stride(0), pos_emb.data_ptr(), pos_emb.stride(0), pos_ids.data_ptr(), neg_rows.data_ptr(),
+            neg_ids.data_ptr(), table.data_ptr(), table.stride(0), table.shape[0], n, neg_rows.shape[1], D, float(temperature),
+            int(pos_l2_norm), int(table_l2_norm), float(eps), lse.data_ptr(), g_row.data_ptr(), dq.data_ptr(), dq.stride(0),
+            dpos.data_ptr(), dpos.stride(0), dtable.data_ptr(), L.torch_dtype_code(q.dtype), L.current_stream_ptr(q.device)))
+    return dq, dpos, dtable

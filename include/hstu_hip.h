@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 3
+#define HSTU_ABI_VERSION 4
 
 enum {
   HSTU_OK = 0,
@@ -245,6 +245,35 @@ int hstu_embedding_grad_segment_sum(const void* dout, const int64_t* sorted_rows
 int hstu_l2_norm_fwd(const void* x, void* y, int64_t rows, int32_t dim, float eps, int dtype, void* stream);
 int hstu_l2_norm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t dim, float eps, int dtype,
                      void* stream);
+
+/* ---- sampled-softmax loss, dot-product similarity --------------------------------------
+ * Per supervision row i (n_rows of them):
+ *   l_i0 = <q_i, P(pos_emb_i)> / T,  l_ik = <q_i, N(table[neg_rows[i,k]])> / T  for k < num_negatives,
+ *   l_ik = -5e4 where neg_ids[i,k] == pos_ids[i];  row_loss_i = logsumexp_k(l_i0, l_i1 ..) - l_i0,  lse_i = that logsumexp;
+ *   P / N = x / max(||x||_2, eps) when pos_l2_norm / table_l2_norm, identity otherwise.
+ * Replaces SampledSoftmaxLoss.jagged_forward (research/modeling/sequential/losses/sampled_softmax.py:44-95) with the
+ * DotProductSimilarity (research/rails/similarities/dot_product_similarity_fn.py:38-62): the caller reduces
+ * sum_i w_i row_loss_i / sum_i w_i.  neg_rows index `table`; neg_ids are the item ids of those rows: the same matrix
+ * for LocalNegativesSampler (autoregressive_losses.py:112-131: table = the item embedding weight, pos/table l2 norm =
+ * the sampler's l2_norm), `cached_ids[offsets]` for InBatchNegativesSampler (:186-204: table = its cached, already
+ * normalised embeddings, table_l2_norm = 0).  q, pos_emb, table: (., dim) in `dtype`, rows 16-byte aligned
+ * (dim a multiple of 4 for fp32 / 8 for 16-bit, dim * elt <= 1024 bytes); ids int64; row_loss, lse fp32 (n_rows).
+ * Indices outside [0, table_rows) are clamped (memory safety only). */
+int hstu_sampled_softmax_fwd(const void* q, int64_t q_row_stride, const void* pos_emb, int64_t pos_row_stride,
+                             const int64_t* pos_ids, const int64_t* neg_rows, const int64_t* neg_ids, const void* table,
+                             int64_t table_row_stride, int64_t table_rows, int64_t n_rows, int32_t num_negatives,
+                             int32_t dim, float temperature, int32_t pos_l2_norm, int32_t table_l2_norm, float eps,
+                             float* row_loss, float* lse, int dtype, void* stream);
+/* Gradients of sum_i grad_row_loss[i] * row_loss_i: dq, dpos_emb (n_rows, dim) in `dtype` (every row written; rows
+ * with grad_row_loss == 0 get zeros and gather nothing), dtable (table_rows, dim) fp32 contiguous, ACCUMULATED into
+ * (zero it first) with atomics -- the one sum of this op whose order is not fixed.  A masked negative passes no
+ * gradient (torch.where picks the constant, sampled_softmax.py:78-82). */
+int hstu_sampled_softmax_bwd(const void* q, int64_t q_row_stride, const void* pos_emb, int64_t pos_row_stride,
+                             const int64_t* pos_ids, const int64_t* neg_rows, const int64_t* neg_ids, const void* table,
+                             int64_t table_row_stride, int64_t table_rows, int64_t n_rows, int32_t num_negatives,
+                             int32_t dim, float temperature, int32_t pos_l2_norm, int32_t table_l2_norm, float eps,
+                             const float* lse, const float* grad_row_loss, void* dq, int64_t dq_row_stride, void* dpos_emb,
+                             int64_t dpos_row_stride, float* dtable, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

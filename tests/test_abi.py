@@ -32,7 +32,7 @@ def lib():
 
 def test_header_symbols_all_exported(lib):
     declared = _declared_symbols()
-    assert len(declared) >= 23
+    assert len(declared) >= 25
     for name in declared:
         assert hasattr(lib, name), f"libhstu_hip.so does not export {name}"
 
@@ -44,7 +44,7 @@ def test_ctypes_signature_table_covers_header():
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.hstu_abi_version() == 3
+    assert lib.hstu_abi_version() == 4
     assert isinstance(lib.hstu_last_error(), bytes)
 
 
