@@ -74,7 +74,50 @@ rows["add_timestamp_positional_embeddings fwd"] = (_enc, 2 * L * D * es + L * 8)
 rows["position-table gradient (sort + segment sum)"] = (lambda: _table_grad(dy, pidx, 8192), L * D * es + 8192 * D * 4)
 rows["l2_norm_fwd (output postprocessor)"] = (lambda: _launch.l2_norm_fwd(x, 1e-6), 2 * L * D * es)
 rows["l2_norm_bwd"] = (lambda: _launch.l2_norm_bwd(dy, x, 1e-6), 3 * L * D * es)
+# sampled-softmax loss at the Amazon-Books shape: 128 users x <= 50 positions, 512 negatives per
+# position, D = 64, 695,762 items, l2 norm, T = 0.05 (configs/amzn-books/hstu-sampled-softmax-n512-final.gin)
+from generative_recommenders_amd.research.modeling.sequential.losses.sampled_softmax import sampled_softmax_row_loss
+SS_N, SS_R, SS_D, SS_V = 4096, 512, 64, 695762
+ss = {}
+for ss_dt, ss_es in ((torch.float32, 4), (torch.bfloat16, 2)):
+    tab = (torch.randn(SS_V, SS_D, device=dev) * 0.1).to(ss_dt).requires_grad_()
+    sq = torch.randn(SS_N, SS_D, device=dev).to(ss_dt).requires_grad_()
+    sids = torch.randint(0, SS_V, (SS_N,), device=dev)
+    spos = tab.detach()[sids].clone().requires_grad_()
+    srows = torch.randint(0, SS_V, (SS_N, SS_R), device=dev)
+    sg = torch.full((SS_N,), 1.0 / SS_N, device=dev)
+    fwd = lambda: sampled_softmax_row_loss(sq, spos, tab, sids, srows, srows, 0.05, True, True, 1e-6)
+    rl = fwd()
+    lse = rl.grad_fn.saved_tensors[-1] if False else None
+    nb_f = SS_N * SS_R * SS_D * ss_es + 2 * SS_N * SS_D * ss_es + 8 * SS_N * SS_R
+    tag = "fp32" if ss_es == 4 else "bf16"
+    rows[f"sampled_softmax fwd ({tag}, 4096 rows x 512 negatives x D=64)"] = (fwd, nb_f)
+    row_loss_k, lse_k = _launch.sampled_softmax_fwd(sq.detach(), spos.detach(), sids, srows, srows, tab.detach(), 0.05, True, True, 1e-6)
+    bwd = (lambda q_=sq.detach(), p_=spos.detach(), t_=tab.detach(), i_=sids, r_=srows, l_=lse_k:
+           _launch.sampled_softmax_bwd(sg, l_, q_, p_, i_, r_, r_, t_, 0.05, True, True, 1e-6))
+    # backward: the gather again + read-modify-write of the same rows in the fp32 gradient table + its zero fill
+    nb_b = nb_f + 2 * SS_N * SS_R * SS_D * 4 + SS_V * SS_D * 4 + 2 * SS_N * SS_D * ss_es
+    rows[f"sampled_softmax bwd ({tag}; incl. zeroing the {SS_V}x{SS_D} fp32 gradient table)"] = (bwd, nb_b)
+    if ss_es == 4:
+        # the reference's algorithm composed from torch ops on the same GPU (sampled_softmax.py:60-93)
+        def torch_ref():
+            ne = tab[srows]
+            ne = ne / torch.clamp(torch.linalg.norm(ne, ord=2, dim=-1, keepdim=True), min=1e-6)
+            pe = spos / torch.clamp(torch.linalg.norm(spos, ord=2, dim=-1, keepdim=True), min=1e-6)
+            lp = (sq * pe).sum(-1, keepdim=True) / 0.05
+            ln = torch.bmm(ne, sq.unsqueeze(2)).squeeze(2)
+            ln = torch.where(sids.unsqueeze(1) == srows, -5e4, ln / 0.05)
+            return (-torch.nn.functional.log_softmax(torch.cat([lp, ln], dim=1), dim=1)[:, 0] * sg).sum()
+        def torch_ref_fb():
+            tab.grad = None; sq.grad = None; spos.grad = None
+            torch_ref().backward()
+        def ours_fb():
+            tab.grad = None; sq.grad = None; spos.grad = None
+            (fwd() * sg).sum().backward()
+        ss = {"torch_composition_fwd_us": round(timed(torch_ref, 5) * 1e6, 1), "torch_composition_fwd_bwd_us": round(timed(torch_ref_fb, 5) * 1e6, 1),
+              "fused_fwd_bwd_us (autograd, incl. table-gradient cast)": round(timed(ours_fb, 5) * 1e6, 1)}
 out = {"shape": {"users": B, "rows": L, "D": D, "heads": H, "dtype": "bf16"}, "peak_GBps": PEAK, "kernels": {}}
+out["sampled_softmax_vs_torch_composition_fp32"] = ss
 for name, (fn, nbytes) in rows.items():
     t = timed(fn)
     out["kernels"][name] = {"us": round(t * 1e6, 1), "algorithmic_bytes": nbytes, "GBps": round(nbytes / t / 1e9, 1),
