@@ -97,6 +97,26 @@ __global__ __launch_bounds__(kCopyThreads) void padded_dense_kernel(char* values
   }
 }
 
+// grid = (ceil(tail / kRowsPerBlock), B): the LAST `tail` rows of every user's region of a jagged buffer are
+// overwritten with the user's `tail` dense rows (the in-place KV-cache append: O(tail), not O(history))
+template <int V>
+__global__ __launch_bounds__(kCopyThreads) void write_tail_kernel(const char* dense, char* values, const void* offsets,
+                                                                  int tail, int row_bytes, int is64) {
+  const int b = blockIdx.y;
+  const int64_t end = load_index(offsets, b + 1, is64);
+  const int r_begin = blockIdx.x * kRowsPerBlock;
+  if (r_begin >= tail) return;
+  const int units = max(row_bytes / V, 1);
+  int tpr = 1;
+  while (tpr < units && tpr < kCopyThreads) tpr <<= 1;
+  const int rows_par = kCopyThreads / tpr;
+  const int t_in_row = threadIdx.x % tpr, my_row_slot = threadIdx.x / tpr;
+  const int r_end = min(r_begin + kRowsPerBlock, tail);
+  for (int r = r_begin + my_row_slot; r < r_end; r += rows_par)
+    copy_row<V>(values + (end - tail + r) * (int64_t)row_bytes, dense + ((int64_t)b * tail + r) * row_bytes, row_bytes,
+                t_in_row, tpr);
+}
+
 // out[0] = 0, out[i+1] = in[0] + ... + in[i].  One workgroup, chunked wave scan with carry
 // (B is at most a few 100k; the op is latency- not bandwidth-bound).
 template <typename I>
@@ -245,6 +265,27 @@ int hstu_dense_to_jagged(const void* dense, void* values, const void* offsets, i
   if (!offsets) return set_error(HSTU_EINVAL, "dense_to_jagged: offsets is NULL");
   return launch_padded<false>((char*)values, (char*)dense, offsets, batch, max_len, dim * elem_bytes,
                               index_dtype == HSTU_INDEX_I64, (hipStream_t)stream);
+}
+
+int hstu_jagged_write_tail(const void* dense, void* values, const void* offsets, int32_t batch, int32_t tail, int32_t dim,
+                           int32_t elem_bytes, int index_dtype, void* stream) {
+  if (batch == 0 || tail == 0 || dim == 0) return HSTU_OK;
+  if (!dense || !values || !offsets) return set_error(HSTU_EINVAL, "jagged_write_tail: NULL tensor");
+  if (batch < 0 || tail < 0 || dim < 0) return set_error(HSTU_EINVAL, "jagged_write_tail: negative size");
+  const int row_bytes = dim * elem_bytes;
+  const int is64 = index_dtype == HSTU_INDEX_I64;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((tail + kRowsPerBlock - 1) / kRowsPerBlock, batch);
+#define LAUNCH(V) hipLaunchKernelGGL((write_tail_kernel<V>), grid, dim3(kCopyThreads), 0, st, (const char*)dense, (char*)values, offsets, tail, row_bytes, is64)
+  switch (pick_vec(row_bytes, dense, values, nullptr)) {
+    case 16: LAUNCH(16); break;
+    case 8: LAUNCH(8); break;
+    case 4: LAUNCH(4); break;
+    case 2: LAUNCH(2); break;
+    default: LAUNCH(1); break;
+  }
+#undef LAUNCH
+  return check_launch("jagged_write_tail");
 }
 
 int hstu_expand_1d_jagged_to_dense(const void* values, const void* offsets, void* dense, int32_t batch, int32_t max_len,

@@ -13,6 +13,7 @@ import torch
 from torch.autograd.profiler import record_function
 
 from generative_recommenders_amd.common import HammerModule
+from generative_recommenders_amd.ops import _launch
 from generative_recommenders_amd.ops.hstu_attention import delta_hstu_mha
 from generative_recommenders_amd.ops.hstu_compute import (
     hstu_compute_output,
@@ -104,6 +105,8 @@ class STULayer(STU):
         self.v_cache: Optional[torch.Tensor] = None
         self.kv_caching_offsets: Optional[torch.Tensor] = None
         self.max_kv_caching_len: int = 0
+        # persistent [cache ; delta] buffers of the in-place append path (see construct_full_kv)
+        self._kv_full: Optional[Tuple[torch.Tensor, torch.Tensor, int, torch.Tensor]] = None
 
     def update_kv_cache(self, max_seq_len: int, seq_offsets: torch.Tensor, k: Optional[torch.Tensor],
                         v: Optional[torch.Tensor], max_kv_caching_len: int,
@@ -118,12 +121,27 @@ class STULayer(STU):
             max_kv_caching_len = int(kv_caching_lengths.max().item())
         self.max_kv_caching_len = max_kv_caching_len
         self.kv_caching_offsets = kv_caching_offsets
+        self._kv_full = None                      # the cache changed: the [cache ; delta] buffers are stale
 
     def construct_full_kv(self, delta_k: torch.Tensor, delta_v: torch.Tensor
                           ) -> Tuple[torch.Tensor, torch.Tensor, int, torch.Tensor]:
+        """[cached rows ; delta rows] per user as one jagged tensor + its offsets (stu.py:134-172).
+
+        The reference rebuilds both tensors with ``concat_2D_jagged`` on every call: O(history) bytes per M-FALCON
+        microbatch and layer.  Under ``torch.no_grad()`` (inference: nothing holds on to earlier results) the buffers of
+        the first call are kept and later calls with the same microbatch size overwrite only the delta rows in place
+        (``hstu_jagged_write_tail``): O(delta).  The returned k / v are then views of those buffers -- valid until the
+        next ``cached_forward`` / ``update_kv_cache`` of this layer, which is all ``cached_forward`` needs."""
         L, _ = delta_k.shape
         B = self.kv_caching_offsets.shape[0] - 1
         delta_size = L // B
+        in_place = not torch.is_grad_enabled() and not (delta_k.requires_grad or delta_v.requires_grad)
+        if in_place and self._kv_full is not None and self._kv_full[2] == delta_size \
+                and self._kv_full[0].dtype == delta_k.dtype:
+            k_full, v_full, _, full_offsets = self._kv_full
+            _launch.jagged_write_tail_(k_full, delta_k, full_offsets, delta_size)
+            _launch.jagged_write_tail_(v_full, delta_v, full_offsets, delta_size)
+            return k_full, v_full, self.max_kv_caching_len + delta_size, full_offsets
         full = []
         for cache, delta in ((self.k_cache, delta_k), (self.v_cache, delta_v)):
             full.append(concat_2D_jagged(
@@ -132,6 +150,8 @@ class STULayer(STU):
                 offsets_left=self.kv_caching_offsets, offsets_right=None))
         full_offsets = self.kv_caching_offsets + delta_size * torch.arange(
             B + 1, device=delta_k.device, dtype=self.kv_caching_offsets.dtype)
+        if in_place:
+            self._kv_full = (full[0], full[1], delta_size, full_offsets)
         return full[0], full[1], self.max_kv_caching_len + delta_size, full_offsets
 
     # ---- forward (stu.py:291-352) ----

@@ -192,6 +192,27 @@ def jagged_to_padded_dense(values, offsets, max_len) -> torch.Tensor:
     return dense
 
 
+def jagged_write_tail_(values: torch.Tensor, dense: torch.Tensor, offsets: torch.Tensor, tail: int) -> torch.Tensor:
+    """IN PLACE: the last ``tail`` rows of every user's region of ``values`` (sum L, ...) <- dense (B * tail, ...)."""
+    L.require_gpu_tensor(values, "values")
+    L.require_gpu_tensor(dense, "dense")
+    if not values.is_contiguous():
+        raise RuntimeError("jagged_write_tail_: the destination must be contiguous (it is written in place)")
+    dense = dense.contiguous()
+    offsets = _idx(offsets)
+    B = offsets.shape[0] - 1
+    dim = values[0].numel() if values.shape[0] else 0
+    if dense.dtype != values.dtype or dense.shape[0] != B * tail or (dense.shape[0] and dense[0].numel() != dim):
+        raise RuntimeError(f"jagged_write_tail_: dense {tuple(dense.shape)} {dense.dtype} does not hold {B} x {tail} rows of values {tuple(values.shape)} {values.dtype}")
+    if B == 0 or tail == 0 or dim == 0:
+        return values
+    with torch.cuda.device(values.device):
+        L.check(L.lib().hstu_jagged_write_tail(dense.data_ptr(), values.data_ptr(), offsets.data_ptr(), B, int(tail), dim,
+                                               values.element_size(), L.index_dtype_code(offsets),
+                                               L.current_stream_ptr(values.device)))
+    return values
+
+
 def dense_to_jagged(dense, offsets, total_rows) -> torch.Tensor:
     L.require_gpu_tensor(dense, "dense")
     d = dense.contiguous()

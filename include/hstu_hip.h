@@ -168,6 +168,14 @@ int hstu_dense_to_jagged(const void* dense, void* values, const void* offsets,
                          int32_t batch, int32_t max_len, int32_t dim, int32_t elem_bytes,
                          int index_dtype, void* stream);
 
+/* In-place KV-cache append: for every user b the LAST `tail` rows of its region
+ * [offsets[b], offsets[b+1]) of the jagged buffer `values` (rows of dim * elem_bytes bytes) are overwritten with
+ * dense[b*tail .. (b+1)*tail).  With it STULayer.cached_forward (modules/stu.py:354-418) writes only the new
+ * microbatch's K/V rows into a persistent [cache ; delta] buffer instead of rebuilding that buffer with
+ * concat_2D_jagged on every call (_construct_full_kv, modules/stu.py:134-172: O(history) bytes per microbatch). */
+int hstu_jagged_write_tail(const void* dense, void* values, const void* offsets, int32_t batch, int32_t tail, int32_t dim,
+                           int32_t elem_bytes, int index_dtype, void* stream);
+
 /* 1-D jagged helpers: hstu::expand_1d_jagged_to_dense
  * (ops/cpp/expand_1d_jagged_to_dense.cu:31-103; pads with the user's LAST value,
  * zeros if empty) and hstu::concat_1d_jagged_jagged

@@ -32,7 +32,7 @@ def lib():
 
 def test_header_symbols_all_exported(lib):
     declared = _declared_symbols()
-    assert len(declared) >= 25
+    assert len(declared) >= 26
     for name in declared:
         assert hasattr(lib, name), f"libhstu_hip.so does not export {name}"
 

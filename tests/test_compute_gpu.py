@@ -207,6 +207,64 @@ def test_stu_cached_forward_equals_full_forward():
         torch.testing.assert_close(inc, full_tail, rtol=1e-4, atol=1e-5)
 
 
+def test_stu_cached_forward_in_place_append_matches_rebuild():
+    """M-FALCON microbatching: several cached_forward calls on one cache.  Under no_grad the [cache ; delta] buffers
+    are kept and only the delta rows are rewritten (hstu_jagged_write_tail); every microbatch must give exactly what
+    the reference's rebuild-by-concat gives (here: the same layer run with grad mode on, which takes the concat path),
+    the cache itself must be untouched, and a changed microbatch size or cache must drop the buffers."""
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig
+    from generative_recommenders_amd.ops.jagged_tensors import asynchronous_complete_cumsum
+
+    torch.manual_seed(3)
+    D, H, A, Hd = 64, 2, 32, 32
+    layer = STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=Hd, attention_dim=A, output_dropout_ratio=0.0,
+                                    target_aware=True, use_group_norm=True), is_inference=True).to(DEV).eval()
+    B, N = 6, 96
+    g = torch.Generator().manual_seed(2)
+    lengths = torch.randint(1, 70, (B,), generator=g).to(DEV)
+    off = asynchronous_complete_cumsum(lengths)
+    x = torch.randn(int(lengths.sum()), D, generator=g).to(DEV)
+    with torch.no_grad():
+        layer(x=x, x_lengths=lengths, x_offsets=off, max_seq_len=N, num_targets=torch.zeros_like(lengths),
+              max_kv_caching_len=N, kv_caching_lengths=lengths)
+    k0, v0 = layer.k_cache.clone(), layer.v_cache.clone()
+    for step, delta in enumerate((16, 16, 16, 8, 8)):
+        dx = torch.randn(B * delta, D, generator=g).to(DEV)
+        nt = torch.full((B,), delta, device=DEV, dtype=lengths.dtype)
+        with torch.no_grad():
+            fast = layer.cached_forward(delta_x=dx, num_targets=nt).clone()
+            assert layer._kv_full is not None and layer._kv_full[2] == delta
+            kept = layer._kv_full[0].data_ptr()
+        with torch.enable_grad():                       # concat path; leaves the persistent buffers alone
+            slow = layer.cached_forward(delta_x=dx, num_targets=nt).detach()
+        assert torch.equal(fast, slow), f"microbatch {step}"
+        assert layer._kv_full[0].data_ptr() == kept
+        assert torch.equal(layer.k_cache, k0) and torch.equal(layer.v_cache, v0)
+    # re-priming the cache drops the buffers
+    with torch.no_grad():
+        layer(x=x, x_lengths=lengths, x_offsets=off, max_seq_len=N, num_targets=torch.zeros_like(lengths),
+              max_kv_caching_len=N, kv_caching_lengths=lengths)
+    assert layer._kv_full is None
+
+
+def test_jagged_write_tail_bit_exact():
+    from generative_recommenders_amd.ops import _launch
+    rng = np.random.default_rng(0)
+    for dtype, dim in ((torch.bfloat16, 64), (torch.float32, 7), (torch.int64, 1), (torch.uint8, 3)):
+        lengths = np.array([5, 0, 9, 3, 3], dtype=np.int64) + 3           # every region holds at least `tail` rows
+        tail = 3
+        off = np.zeros(6, dtype=np.int64); off[1:] = np.cumsum(lengths)
+        base = torch.from_numpy(rng.integers(0, 100, (int(off[-1]), dim))).to(dtype).to(DEV)
+        new = torch.from_numpy(rng.integers(100, 200, (5 * tail, dim))).to(dtype).to(DEV)
+        want = base.clone()
+        for b in range(5):
+            want[off[b + 1] - tail: off[b + 1]] = new[b * tail: (b + 1) * tail]
+        got = _launch.jagged_write_tail_(base, new, torch.from_numpy(off).to(DEV), tail)
+        assert got.data_ptr() == base.data_ptr() and torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        _launch.jagged_write_tail_(base, new[:, :1].float(), torch.from_numpy(off).to(DEV), tail)
+
+
 def test_silu_matches_torch():
     from generative_recommenders_amd.ops import _launch
 
