@@ -30,6 +30,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)      # RCCL binds a communicator to the device current at first use
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
