@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       }
       HSTU_MARK(11);
       Frag pb[2];
-      const int mode = tile_full ? 0 : (mc.simple ? 1 : 2);   // wave-uniform
+      const int mode = tile_full ? 0 : (mc.simple ? 1 : (mc.ctx == 0 ? 3 : 2));   // wave-uniform
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {   // two halves keep only 8 fp32 temporaries live
         float pv[8];
@@ -330,6 +330,17 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
             const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             const bool ok = row_ok & (key < len) & mc.valid_ids(qi, key, qi_id, mc.id_of(key));
             pv[j] = ok ? pv[j] : 0.f;
+          }
+        } else if (mode == 3) {   // targets / window without contextual rows: integer arithmetic, no compare chains
+          const int i_eff = row_ok ? qi : -1;
+          const int idi = mc.has_targets ? min(i_eff, mc.max_id) : i_eff;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * h8 + j;
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const int idj = mc.has_targets ? min(key, mc.max_id) : key;
+            const int keep = mc.keep_bits_row(i_eff, idi, key, idj) & ((key - len) >> 31);
+            pv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, pv[j]) & keep);
           }
         }
         pb[h8] = E::pack8(pv);

@@ -221,6 +221,10 @@ struct MaskCtx {
   HSTU_DEV int keep_bits_noctx(int i, int j, int idj) const {
     const int i_eff = i | ((len - 1 - i) >> 31);               // i, or -1 when i >= len
     const int idi = has_targets ? min(i_eff, max_id) : i_eff;
+    return keep_bits_row(i_eff, idi, j, idj);
+  }
+  // the same with the row side (i_eff, idi as above) precomputed: the forward's lanes own one query row each
+  HSTU_DEV int keep_bits_row(int i_eff, int idi, int j, int idj) const {
     const int d = idi - idj;
     const int x = i_eff ^ j;
     int m = (~(x | -x) >> 31) | ((-d) >> 31);                  // (i == j) | (d > 0)
