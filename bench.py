@@ -192,7 +192,9 @@ def cpu_baseline(args):
     v = torch.empty(L, H, d).uniform_(-0.01, 0.01, generator=gen).requires_grad_()
     do = torch.randn(L, H, d, generator=gen)
     times = []
-    for i in range(3):
+    # one warm-up pass, then timed passes over the same chunk until ~10 s of CPU work are on the clock
+    # (bounded: the default bench run must stay within minutes whatever the host is)
+    while len(times) < 2 or (sum(times[1:]) < 10.0 and len(times) < 41):
         t0 = time.perf_counter()
         out = dense_hstu_mha(N, d**-0.5, q, k, v, off)
         out.backward(do)
@@ -200,8 +202,9 @@ def cpu_baseline(args):
         q.grad = k.grad = v.grad = None
     med = statistics.median(times[1:])
     return dict(value=B / med, unit="user-seqs/s", cores=cores, kind="port",
-                sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of 2 after 1 warm-up "
-                       f"({med * 1e3:.0f} ms each); oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
+                sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of {len(times) - 1} passes "
+                       f"after 1 warm-up ({med * 1e3:.0f} ms each, {sum(times[1:]):.1f} s of CPU work); "
+                       f"oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
 
 
 def bwd_kernel_name(args) -> str:
