@@ -287,18 +287,15 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     if (wave_active && tile_act) {
       const char* Kt = smem + (t % C::NS) * C::STAGE;
       const char* Vt = Kt + C::KT;
-      f32x16 s, s1;   // two accumulators halve the dependent-MFMA chain of the QK^T contraction
+      // ONE accumulator chain: back-to-back dependent MFMAs forward their result, and the VALU cycles a second chain
+      // costs (16 adds per tile and lane) are what the long-sequence forward is bound by (N = 8192: +2..4 %)
+      f32x16 s;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; s1[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int kg = 0; kg < C::KG; ++kg) {
         Frag a = lds_row_frag<T, C::UPR_K>(Kt, n32, hf * (DQK / 2) + kg * 8);
-        if (kg & 1) s1 = E::mma(a, qf[kg], s1);
-        else s = E::mma(a, qf[kg], s);
-      }
-      if constexpr (C::KG > 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += s1[r];
+        s = E::mma(a, qf[kg], s);
       }
       HSTU_MARK(11);
       Frag pb[2];
