@@ -122,6 +122,29 @@ for name, (fn, nbytes) in rows.items():
     t = timed(fn)
     out["kernels"][name] = {"us": round(t * 1e6, 1), "algorithmic_bytes": nbytes, "GBps": round(nbytes / t / 1e9, 1),
                             "frac_of_hbm_peak": round(nbytes / t / 1e9 / PEAK, 3)}
+# the two projections (MFMA-bound rows a7 / a8): hipBLASLt through torch, fwd + data gradient + weight gradient
+from generative_recommenders_amd.ops.mm import weight_grad_mm
+MFMA_PEAK = 2500.0   # dense bf16 TFLOP/s (MI355X_MICROARCH.md)
+Wu = torch.randn(D, 4 * D, device=dev, dtype=bf) * 0.02
+bu = torch.zeros(4 * D, device=dev, dtype=bf)
+Wo = torch.randn(3 * D, D, device=dev, dtype=bf) * 0.02
+g4 = torch.randn(L, 4 * D, device=dev, dtype=bf)
+gemms = {
+    "uvqk fwd  (L x 512)(512 x 2048) addmm": (lambda: torch.addmm(bu, x, Wu), 2.0 * L * D * 4 * D),
+    "uvqk dgrad (L x 2048)(2048 x 512)": (lambda: torch.mm(g4, Wu.t()), 2.0 * L * D * 4 * D),
+    "uvqk wgrad (512 x L)(L x 2048) split-K": (lambda: weight_grad_mm(x, g4), 2.0 * L * D * 4 * D),
+    "output fwd (L x 1536)(1536 x 512)": (lambda: torch.mm(dy3, Wo), 2.0 * L * 3 * D * D),
+    "output dgrad (L x 512)(512 x 1536)": (lambda: torch.mm(dy, Wo.t()), 2.0 * L * 3 * D * D),
+    "output wgrad (1536 x L)(L x 512) split-K": (lambda: weight_grad_mm(dy3, dy), 2.0 * L * 3 * D * D),
+}
+out["projections"] = {"mfma_peak_TFLOPs": MFMA_PEAK, "gemms": {}}
+tot_f = tot_t = 0.0
+for name, (fn, fl) in gemms.items():
+    t = timed(fn)
+    tot_f += fl; tot_t += t
+    out["projections"]["gemms"][name] = {"us": round(t * 1e6, 1), "TFLOPs": round(fl / t / 1e12, 1), "frac_of_mfma_peak": round(fl / t / 1e12 / MFMA_PEAK, 3)}
+out["projections"]["all_six"] = {"us": round(tot_t * 1e6, 1), "TFLOPs": round(tot_f / tot_t / 1e12, 1), "frac_of_mfma_peak": round(tot_f / tot_t / 1e12 / MFMA_PEAK, 3)}
+
 # CPU leg: the torch CPU equivalents of the two heaviest row kernels on a 128-user sample
 torch.set_num_threads(min(32, os.cpu_count() or 1))
 n = int(off[128])
