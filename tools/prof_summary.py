@@ -22,6 +22,15 @@ def main(root):
         print("## kernel trace (--kernel-trace --stats)\n\n| kernel | calls | avg us | total us | % |\n|---|---|---|---|---|")
         for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 8"):
             print(f"| {name[:70]} | {calls} | {avg:.1f} | {total:.0f} | {pct:.1f} |")
+        # steady state: the timed launches of bench.py are the LAST `steps` dispatches of each attention kernel (the
+        # first ones are its warm-up, at ramping clocks); bench.py's HIP-event figure is over exactly those
+        print("\n| kernel | dispatches | avg us, all | avg us, warm-up excluded | median us |\n|---|---|---|---|---|")
+        for (name,) in list(cur.execute("select distinct name from kernels where name like '%hstu_attn%'")):
+            d = [r[0] / 1e3 for r in cur.execute("select duration from kernels where name = ? order by start", (name,))]
+            warm = int(os.environ.get("PROF_WARMUP", "2"))
+            tail = d[warm:] if len(d) > warm else d
+            sd = sorted(tail)
+            print(f"| {name[:70]} | {len(d)} | {sum(d) / len(d):.1f} | {sum(tail) / len(tail):.1f} | {sd[len(sd) // 2]:.1f} |")
         rows = list(cur.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels where name like '%hstu_attn%' group by name"))
         print("\n| kernel | arch VGPR | accum VGPR | SGPR | LDS bytes | grid | block |\n|---|---|---|---|---|---|---|")
         for r in rows:
