@@ -88,6 +88,25 @@ def _mha_impl(*args):
     return _HstuMhaOp.apply(*args)
 
 
+def sort_kv_pairs(keys: torch.Tensor, values: torch.Tensor, end_bit=None, descending: bool = False):
+    """``hstu::sort_kv_pairs`` (ops/cpp/cpp_ops.cpp:73-101, sort_kv_pairs_cuda_kernels_template.cu:9-77): stable
+    radix sort of 1-D (key, value) pairs on key bits [0, end_bit) -- all bits when ``end_bit`` is None.  Index
+    plumbing: the sort itself is torch's (rocPRIM radix sort on the GPU), as the reference's is cub's."""
+    if keys.dtype not in (torch.int32, torch.int64, torch.uint8, torch.int16):
+        raise RuntimeError("sort_kv_pairs: keys must be int32, int64, uint8 or int16")
+    if keys.dim() != 1 or values.dim() != 1 or keys.shape != values.shape:
+        raise RuntimeError("sort_kv_pairs: keys and values must be 1-D tensors of one length")
+    width = keys.element_size() * 8
+    if end_bit is None or end_bit >= width:
+        sub = keys
+    else:
+        if end_bit <= 0:
+            return keys.clone(), values.clone()          # no key bits: a stable sort leaves the order alone
+        sub = keys.to(torch.int64) & ((1 << int(end_bit)) - 1)
+    order = torch.sort(sub, stable=True, descending=bool(descending)).indices
+    return keys[order], values[order]
+
+
 def register() -> None:
     """Idempotent; raises if another library (e.g. the reference's CUDA extension) already owns
     the ``hstu`` schemas."""
@@ -115,6 +134,8 @@ def register() -> None:
     lib.define("concat_1d_jagged_jagged(Tensor lengths_left, Tensor values_left, Tensor lengths_right, "
                "Tensor values_right) -> Tensor")
 
+    lib.define("sort_kv_pairs(Tensor keys, Tensor values, int? end_bit=None, bool descending=False) -> (Tensor, Tensor)")
+
     lib.impl("hstu_mha_fwd", _fwd_impl, "CUDA")
     lib.impl("hstu_mha_bwd", _bwd_impl, "CUDA")
     lib.impl("hstu_mha", _mha_impl, "CompositeImplicitAutograd")
@@ -123,6 +144,8 @@ def register() -> None:
              lambda values, offsets, max_len: _launch.expand_1d_jagged_to_dense(values, offsets, int(max_len)), "CUDA")
     lib.impl("concat_1d_jagged_jagged",
              lambda ll, vl, lr, vr: _launch.concat_1d_jagged_jagged(ll, vl, lr, vr), "CUDA")
+
+    lib.impl("sort_kv_pairs", sort_kv_pairs, "CompositeExplicitAutograd")
 
     # Meta (shape-only) kernels, as flash_meta.cpp provides for tracing
     def _fwd_meta(max_seq_len, alpha, q, k, v, *rest):

@@ -161,3 +161,25 @@ def test_module_state_dict_names_match_reference():
         "_output_norm_weight", "_output_norm_bias"])
     assert layer._uvqk_weight.shape == (16, 64) and layer._output_weight.shape == (48, 16)
     assert layer._output_norm_weight.shape == (2,)
+
+
+def test_sort_kv_pairs_operator_semantics():
+    """hstu::sort_kv_pairs (ops/cpp/cpp_ops.cpp:101): stable, optional low-bit key range, both directions -- checked
+    against a python sort on CPU tensors (the op is index plumbing on torch.sort and runs on any device)."""
+    import torch
+    from generative_recommenders_amd.ops import torch_library
+
+    torch_library.register()
+    g = torch.Generator().manual_seed(0)
+    keys = torch.randint(-50, 50, (200,), generator=g)
+    vals = torch.arange(200)
+    for desc in (False, True):
+        k, v = torch.ops.hstu.sort_kv_pairs(keys, vals, None, desc)
+        want = sorted(range(200), key=lambda i: (-keys[i].item() if desc else keys[i].item(), i))
+        assert v.tolist() == want and k.tolist() == [keys[i].item() for i in want]
+        k4, v4 = torch.ops.hstu.sort_kv_pairs(keys, vals, 4, desc)
+        sub = lambda i: keys[i].item() & 15
+        want4 = sorted(range(200), key=lambda i: (-sub(i) if desc else sub(i), i))
+        assert v4.tolist() == want4 and k4.tolist() == [keys[i].item() for i in want4]
+    k0, v0 = torch.ops.hstu.sort_kv_pairs(keys.int(), vals.float(), 0, False)
+    assert k0.tolist() == keys.tolist() and v0.dtype == torch.float32
