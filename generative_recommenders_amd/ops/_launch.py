@@ -414,3 +414,4 @@ def sampled_softmax_bwd(g_row, lse, q, pos_emb, pos_ids, neg_rows, neg_ids, tabl
             int(pos_l2_norm), int(table_l2_norm), float(eps), lse.data_ptr(), g_row.data_ptr(), dq.data_ptr(), dq.stride(0),
             dpos.data_ptr(), dpos.stride(0), dtable.data_ptr(), L.torch_dtype_code(q.dtype), L.current_stream_ptr(q.device)))
     return dq, dpos, dtable
+
