@@ -12,11 +12,13 @@ static int launch_fwd_inst(const HstuAttnParams& p, hipStream_t st) {
   const int nqb = (q_rows + kFwdRowsPerBlock - 1) / kFwdRowsPerBlock;
   const int groups = (p.batch * p.heads + 7) / 8;
   auto kern = hstu_attn_fwd_kernel<T, DQK, DV, BIAS>;
-  if (C::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-    if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_fwd: cannot reserve %d bytes of LDS: %s", C::SMEM, hipGetErrorString(e));
+  const int smem = C::SMEM + (BIAS ? bias_table_bytes(p.max_seq_len, p.num_buckets) : 0);   // tables staged behind the ring
+  if (smem > kLdsBudget) return set_error(HSTU_EUNSUPPORTED, "hstu_attn_fwd: max_seq_len %d needs %d bytes of LDS for the bias tables", p.max_seq_len, smem);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_fwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(groups * 8 * nqb), dim3(kFwdThreads), C::SMEM, st, p, nqb);
+  hipLaunchKernelGGL(kern, dim3(groups * 8 * nqb), dim3(kFwdThreads), smem, st, p, nqb);
   return check_launch("hstu_attn_fwd");
 }
 
@@ -50,10 +52,6 @@ static int launch_fwd_dtype(const HstuAttnParams& p, hipStream_t st) {
   return set_error(HSTU_EUNSUPPORTED, "hstu_attn_fwd: head dims (%d, %d) not instantiated", p.dqk, p.dv);
 }
 
-static inline int bias_hist_bytes(const HstuAttnParams& p) {
-  return p.pos_w ? ((2 * p.max_seq_len + p.num_buckets) * 4 + 15) / 16 * 16 : 0;
-}
-
 template <typename T, int DQK, int DV>
 static int bwd_tiles_inst(int max_seq_len, int extra_lds) {
   using C = BwdCfg<T, DQK, DV>;
@@ -69,7 +67,8 @@ template <typename T, int DQK, int DV, bool BIAS>
 static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   using C = BwdCfg<T, DQK, DV>;
   const HstuAttnParams& p = bp.fwd;
-  const int hist = bias_hist_bytes(p);
+  int ts_copies = 1;
+  const int hist = attn_bwd_bias_lds(p, &ts_copies);
   const int nw = bwd_tiles_inst<T, DQK, DV>(p.max_seq_len, hist);
   const int nkb = (p.max_seq_len + 32 * nw - 1) / (32 * nw);
   const int groups = (p.batch * p.heads + 7) / 8;
@@ -97,7 +96,7 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
     hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblocks * hw * sizeof(float), st);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial, ts_copies);
   if (int e = check_launch("hstu_attn_bwd")) return e;
   if (nkb > 1) {
     const int64_t n = bp.total_rows * p.heads * (int64_t)(p.dqk / (16 / Elem<T>::kBytes));   // 16 bytes of dq per thread

@@ -27,9 +27,27 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 
+// Time buckets are few and lopsided (most pairs of a user fall in the top three or four): the lanes of a wave mostly
+// add to the SAME histogram entry and the LDS atomics serialise.  Every lane group therefore gets its own copy of
+// the time-bucket histogram (entry b of copy c at b * copies + c: the lanes of a wave that share a bucket hit
+// consecutive words), as many copies as fit without costing a key tile; the copies are summed at the flush.
+int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies) {
+  if (ts_copies) *ts_copies = 1;
+  if (!p.pos_w) return 0;
+  auto bytes = [&](int nc) {
+    return ((2 * p.max_seq_len + (p.num_buckets + 1) * nc) * 4 + 15) / 16 * 16 + bias_table_bytes(p.max_seq_len, p.num_buckets);
+  };
+  const int base = attn_bwd_tiles_per_block(p.dtype, p.dqk, p.dv, p.max_seq_len, bytes(1));
+  int nc = 1;
+  for (int c : {32, 8})
+    if (attn_bwd_tiles_per_block(p.dtype, p.dqk, p.dv, p.max_seq_len, bytes(c)) == base) { nc = c; break; }
+  if (ts_copies) *ts_copies = nc;
+  return bytes(nc);
+}
+
 size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& bp) {
   const HstuAttnParams& p = bp.fwd;
-  const int hist = p.pos_w ? ((2 * p.max_seq_len + p.num_buckets) * 4 + 15) / 16 * 16 : 0;
+  const int hist = attn_bwd_bias_lds(p, nullptr);
   const int nw = attn_bwd_tiles_per_block(p.dtype, p.dqk, p.dv, p.max_seq_len, hist);
   if (nw <= 0) return 0;
   const int nkb = (p.max_seq_len + 32 * nw - 1) / (32 * nw);
@@ -37,33 +55,51 @@ size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& bp) {
   if (nkb > 1) bytes += ((size_t)bp.total_rows * p.heads * p.dqk * sizeof(float) + 255) / 256 * 256;
   if (p.pos_w) {
     const size_t nblocks = (size_t)((p.batch * p.heads + 7) / 8) * 8 * nkb;
-    bytes += nblocks * (2 * p.max_seq_len + p.num_buckets) * sizeof(float);
+    bytes += (nblocks + 128) * (2 * p.max_seq_len + p.num_buckets) * sizeof(float);   // + the reduce's 128 chunk-sum rows
   }
   return bytes;
 }
 
-// column sums of the (rows, width) partial matrix; one thread per column, rows walked in order
-// (deterministic across launches)
-__global__ void bias_grad_reduce_kernel(const float* partial, int rows, int width, int npos, float* dpos_w, float* dts_w) {
+// column sums of the (rows, width) partial matrix in two fixed-order stages (deterministic across launches):
+// stage 1, grid (column blocks, kRedChunks): every workgroup sums its contiguous chunk of rows for 64 columns into
+// row `chunk` of the chunk-sum rows that follow the partial rows in the workspace; stage 2: one thread per column
+// sums the kRedChunks chunk rows.  (One thread per column over ALL rows -- the first version -- took 3.6 ms for the
+// 32768 partial rows of an 8192-user batch: 9 waves on the whole chip.)
+constexpr int kRedChunks = 128;
+
+__global__ void bias_grad_reduce_stage1(const float* partial, int rows, int width, float* chunk_sums) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= width) return;
+  const int per = (rows + kRedChunks - 1) / kRedChunks;
+  const int r0 = blockIdx.y * per, r1 = min(r0 + per, rows);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 3 < rows; r += 4) {
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
     s0 += partial[(int64_t)r * width + c];
     s1 += partial[(int64_t)(r + 1) * width + c];
     s2 += partial[(int64_t)(r + 2) * width + c];
     s3 += partial[(int64_t)(r + 3) * width + c];
   }
-  for (; r < rows; ++r) s0 += partial[(int64_t)r * width + c];
-  const float s = (s0 + s1) + (s2 + s3);
+  for (; r < r1; ++r) s0 += partial[(int64_t)r * width + c];
+  chunk_sums[(int64_t)blockIdx.y * width + c] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void bias_grad_reduce_stage2(const float* chunk_sums, int chunks, int width, int npos, float* dpos_w, float* dts_w) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int r = 0; r < chunks; ++r) s += chunk_sums[(int64_t)r * width + c];
   if (c < npos) dpos_w[c] = s;
   else if (dts_w) dts_w[c - npos] = s;
 }
 
 int launch_bias_grad_reduce(const float* partial, int rows, int width, int npos, float* dpos_w, float* dts_w,
                             hipStream_t st) {
-  hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((width + 63) / 64), dim3(64), 0, st, partial, rows, width, npos, dpos_w, dts_w);
-  return check_launch("hstu_attn_bwd(bias gradient reduce)");
+  // the chunk sums live right behind the partial rows (attn_bwd_workspace_bytes reserves kRedChunks extra rows)
+  float* chunk_sums = const_cast<float*>(partial) + (size_t)rows * width;
+  hipLaunchKernelGGL(bias_grad_reduce_stage1, dim3((width + 63) / 64, kRedChunks), dim3(64), 0, st, partial, rows, width, chunk_sums);
+  if (int e = check_launch("hstu_attn_bwd(bias gradient reduce 1)")) return e;
+  hipLaunchKernelGGL(bias_grad_reduce_stage2, dim3((width + 63) / 64), dim3(64), 0, st, chunk_sums, kRedChunks, width, npos, dpos_w, dts_w);
+  return check_launch("hstu_attn_bwd(bias gradient reduce 2)");
 }
 }  // namespace hstu

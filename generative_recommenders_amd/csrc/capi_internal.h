@@ -30,8 +30,15 @@ int launch_bias_grad_reduce(const float* partial, int rows, int width, int npos,
                             hipStream_t st);
 size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& p);
 int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int extra_lds);
+// LDS bytes of the research-path bias state of a backward workgroup (histograms with *ts_copies privatised copies of
+// the time-bucket histogram + the staged tables) and the number of copies chosen; 0 without bias
+int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies);
 
 inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }
 constexpr int kLdsBudget = 160 * 1024;
+// bytes of the bias tables a workgroup stages in LDS: pos_w (2N-1 floats), ts_w (nb+1 floats), N int64 timestamps
+inline int bias_table_bytes(int max_seq_len, int num_buckets) {
+  return ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16) * 16 + max_seq_len * 8;
+}
 constexpr int kDqScratchBytes = 8 * 4096;   // general backward, several key blocks: one [32 q][32 d] fp32 tile per wave
 }  // namespace hstu

@@ -197,7 +197,7 @@ HSTU_DEV void bwd_dq_tile(const HstuAttnBwdParams& bp, const MaskCtx& mc, const 
 
 template <typename T, int DQK, int DV, bool BIAS = false>
 __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAttnBwdParams bp, int nkb, int nw,
-                                                                    float* dq_accum, float* bias_partial) {
+                                                                    float* dq_accum, float* bias_partial, int ts_copies) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -238,11 +238,14 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   BiasCtx bc;
   // several key blocks: a [32 q][32 d] fp32 tile per wave for the coalesced dq adds, then the bias histograms
   char* const dq_scratch = dsbuf + 2 * nw * C::DSBUF + wave * (kDqScratchBytes / kBwdWaves);
+  // [pos histogram, 2N floats][time-bucket histogram, (nb+1) x ts_copies][staged tables]
   float* const hpos = (float*)(dsbuf + 2 * nw * C::DSBUF + (nkb > 1 ? kDqScratchBytes : 0));
-  float* const hts = hpos + (2 * p.max_seq_len - 1);
+  float* const hts = hpos + 2 * p.max_seq_len;
+  const int hist_floats = 2 * p.max_seq_len + (p.num_buckets + 1) * ts_copies;
+  const int my_copy = lane & (ts_copies - 1);
   if constexpr (BIAS) {
-    bc = make_bias_ctx(p, b);
-    for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) hpos[i] = 0.f;
+    bc = stage_bias_tables(p, b, (char*)hpos + (hist_floats * 4 + 15) / 16 * 16, tid, kBwdThreads);
+    for (int i = tid; i < hist_floats; i += kBwdThreads) hpos[i] = 0.f;
   }
 
   const char* qbase = (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
@@ -292,7 +295,25 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const bool key_ok = tile_owner && key < len;
   const int key_id = mc.id_of(key);
   int64_t t_k = 0;
-  if constexpr (BIAS) t_k = bc.ts_at(key);
+  if constexpr (BIAS) {
+    const int64_t* tr = bias_ts_row(p, b);
+    t_k = tr ? tr[min(max(key, 0), p.max_seq_len - 1)] : 0;   // (the staged copy is not visible before the barrier)
+  }
+
+  // Time-bucket histogram: a lane owns ONE key for the whole kernel and walks its query rows in order, so the time
+  // difference -- and with it the (logarithmic) bucket -- changes only a handful of times per tile.  The running sum of
+  // the current bucket stays in a register and goes to the LDS histogram when the bucket changes (LDS float atomics
+  // cost ~200 cycles per wave instruction here; one per element was half of this kernel's time).
+  int ts_cur = 0;
+  float ts_sum = 0.f;
+  auto ts_cache_add = [&](int bkt_, float v_) {
+    if (bkt_ != ts_cur) {
+      if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
+      ts_cur = bkt_;
+      ts_sum = 0.f;
+    }
+    ts_sum += v_;
+  };
 
   for (int it = it_hi - 1; it >= it_lo; --it) {
     const int i0 = it << 5;
@@ -375,20 +396,28 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           }
         }
         if constexpr (BIAS) {
-          // d bias = dS (summed over heads / users later); masked-out elements carry exact zeros
-          if (mode == 0) {
+          // d bias = dS (summed over heads / users later); masked-out elements carry exact zeros.
+          // Position histogram: bin = n-1 + key - query.  The 4 consecutive query rows of a register group (j = 0..3)
+          // of the 4 consecutive keys held by lanes l .. l+3 lie on ONE diagonal: lane l collects them with three DPP
+          // row shifts and issues one atomic instead of four (LDS float atomics cost ~200 cycles per instruction
+          // here).  What a shift pushes out of a 16-lane row (the first j lanes of a row for element j) is added by its
+          // owner: three more instructions with 4 / 8 / 12 active lanes.
+          const int p16 = lane & 15;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              atomicAdd(hpos + pidx[j], dsv[j]);
-              if (bc.ts_w) atomicAdd(hts + bkt[j], dsv[j]);
-            }
-          } else {
+          for (int gg = 0; gg < 2; ++gg) {
+            float t = dsv[4 * gg + 3];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (dsv[j] != 0.f) {
-                atomicAdd(hpos + pidx[j], dsv[j]);
-                if (bc.ts_w) atomicAdd(hts + bkt[j], dsv[j]);
-              }
+            for (int j = 2; j >= 0; --j)
+              t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x101, 0xf, 0xf, true)) +
+                  dsv[4 * gg + j];
+            if (t != 0.f) atomicAdd(hpos + pidx[4 * gg], t);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+              if (p16 < j && dsv[4 * gg + j] != 0.f) atomicAdd(hpos + pidx[4 * gg + j], dsv[4 * gg + j]);
+          }
+          if (bc.lts) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ts_cache_add(bkt[j], dsv[j]);
           }
         }
         pb[h8] = E::pack8(pv);
@@ -464,8 +493,21 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   }
   HSTU_MARK(21);
   if constexpr (BIAS) {
+    if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
+    __syncthreads();
     float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
-    for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) row[i] = hpos[i] * p.scale;
+    const int npos = 2 * p.max_seq_len - 1;
+    for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) {
+      float v;
+      if (i < npos) {
+        v = hpos[i];
+      } else {
+        v = 0.f;
+        const float* cp = hts + (i - npos) * ts_copies;
+        for (int c = 0; c < ts_copies; ++c) v += cp[c];
+      }
+      row[i] = v * p.scale;
+    }
   }
   // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv.  16-bit I/O with the
   // instantiated head dims: through LDS -- each owner wave writes its two [32 keys][D] tiles over its own (dead) K/V

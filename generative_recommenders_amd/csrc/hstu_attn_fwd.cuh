@@ -202,8 +202,12 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   BiasCtx bc;
   int64_t t_q1 = 0;
   if constexpr (BIAS) {
-    bc = make_bias_ctx(p, b);
-    t_q1 = bc.ts_at(qi + 1);   // the row uses the NEXT item's timestamp
+    // tables + this user's timestamps -> LDS behind the K/V ring (every thread of the workgroup is here: the early
+    // returns above are workgroup-uniform)
+    bc = stage_bias_tables(p, b, smem + C::SMEM, tid, kFwdThreads);
+    const int64_t* tr = bias_ts_row(p, b);
+    t_q1 = tr ? tr[min(max(qi + 1, 0), p.max_seq_len - 1)] : 0;   // the row uses the NEXT item's timestamp
+    lds_barrier();
   }
 
   // ---- key range visited by this workgroup (conservative; the per-element mask is exact)
