@@ -36,9 +36,11 @@ int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies);
 
 inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }
 constexpr int kLdsBudget = 160 * 1024;
-// bytes of the bias tables a workgroup stages in LDS: pos_w (2N-1 floats), ts_w (nb+1 floats), N int64 timestamps
+// bytes of the bias tables a workgroup stages in LDS: pos_w (2N-1 floats), ts_w (nb+1 floats), N int64 timestamps,
+// their int32 offsets
 inline int bias_table_bytes(int max_seq_len, int num_buckets) {
-  return ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16) * 16 + max_seq_len * 8;
+  return ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16) * 16 + max_seq_len * 8 +
+         (max_seq_len * 4 + 8 * 4 + 15) / 16 * 16;   // + int32 offsets and one range flag per wave
 }
 constexpr int kDqScratchBytes = 8 * 4096;   // general backward, several key blocks: one [32 q][32 d] fp32 tile per wave
 }  // namespace hstu

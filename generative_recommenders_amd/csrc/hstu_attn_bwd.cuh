@@ -295,9 +295,11 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const bool key_ok = tile_owner && key < len;
   const int key_id = mc.id_of(key);
   int64_t t_k = 0;
-  if constexpr (BIAS) {
-    const int64_t* tr = bias_ts_row(p, b);
-    t_k = tr ? tr[min(max(key, 0), p.max_seq_len - 1)] : 0;   // (the staged copy is not visible before the barrier)
+  int t_k32 = 0;
+  if constexpr (BIAS) {   // (after the barrier above: the staged tables are visible)
+    bc.finish(kBwdWaves);
+    t_k = bc.ts_at(key);
+    if (bc.small) t_k32 = bc.t32_at(key);
   }
 
   // Time-bucket histogram: a lane owns ONE key for the whole kernel and walks its query rows in order, so the time
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           if constexpr (BIAS) {
             const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             pidx[j] = bc.pos_index(qi, key);
-            bkt[j] = bc.bucket(bc.ts_at(qi + 1), t_k);
+            bkt[j] = bc.small ? bc.bucket32(bc.t32_at(qi + 1), t_k32) : bc.bucket(bc.ts_at(qi + 1), t_k);   // wave-uniform choice
             x += bc.value(pidx[j], bkt[j]);
           }
           const float sg = fast_sigmoid(x);

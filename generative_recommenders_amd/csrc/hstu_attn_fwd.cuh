@@ -201,6 +201,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   const int qi_id = mc.id_of(qi);
   BiasCtx bc;
   int64_t t_q1 = 0;
+  int t_q32 = 0;
   if constexpr (BIAS) {
     // tables + this user's timestamps -> LDS behind the K/V ring (every thread of the workgroup is here: the early
     // returns above are workgroup-uniform)
@@ -208,6 +209,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     const int64_t* tr = bias_ts_row(p, b);
     t_q1 = tr ? tr[min(max(qi + 1, 0), p.max_seq_len - 1)] : 0;   // the row uses the NEXT item's timestamp
     lds_barrier();
+    bc.finish(kFwdThreads / 64);
+    if (bc.small) t_q32 = bc.t32_at(qi + 1);
   }
 
   // ---- key range visited by this workgroup (conservative; the per-element mask is exact)
@@ -313,7 +316,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
           if constexpr (BIAS) {
             const int r = 8 * h8 + j;
             const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            x += bc.value(bc.pos_index(qi, key), bc.bucket(t_q1, bc.ts_at(key)));
+            const int bkt = bc.small ? bc.bucket32(t_q32, bc.t32_at(key)) : bc.bucket(t_q1, bc.ts_at(key));   // wave-uniform choice
+            x += bc.value(bc.pos_index(qi, key), bkt);
           }
           pv[j] = x * fast_sigmoid(x);
         }

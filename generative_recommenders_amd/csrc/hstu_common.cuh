@@ -290,10 +290,18 @@ struct BiasCtx {
   const char* lpos;    // LDS: pos_w, 2n-1 floats
   const char* lts;     // LDS: ts_w, nb+1 floats, or nullptr (position-only bias)
   const char* ltime;   // LDS: this user's n timestamps (int64), or nullptr
+  const char* lt32;    // LDS: the same as int32 offsets from the row's first timestamp, then one "out of range" word per wave
   int n, nb;
+  bool small;          // every offset fits 30 bits: time differences are formed and converted in 32-bit arithmetic
   float div, kf;       // kf = ln 2 / div: bucket coordinate = log2(d) * kf
   HSTU_DEV int64_t ts_at(int pos) const {
     return ltime ? *LDS_PTR(const int64_t, ltime + 8 * min(max(pos, 0), n - 1)) : 0;
+  }
+  HSTU_DEV int t32_at(int pos) const { return *LDS_PTR(const int, lt32 + 4 * min(max(pos, 0), n - 1)); }
+  // after the barrier that follows stage_bias_tables: did any wave see an offset outside 30 bits?
+  HSTU_DEV void finish(int nwaves) {
+    small = ltime != nullptr;
+    for (int w = 0; w < nwaves; ++w) small = small && (*LDS_PTR(const int, lt32 + 4 * (n + w)) == 0);
   }
   HSTU_DEV int pos_index(int qi, int key) const { return min(max(n - 1 + key - qi, 0), 2 * n - 2); }
   // bucket(d) = clamp((int)(logf((float)max(|d|, 1)) / div), 0, nb), exactly: the coordinate is first formed with the
@@ -306,7 +314,16 @@ struct BiasCtx {
     int64_t d = t_q1 - t_k;
     d = d < 0 ? -d : d;
     d = d < 1 ? 1 : d;
-    const float x = (float)d;
+    return bucket_of((float)d);
+  }
+  // the same from 32-bit offsets (|difference| < 2^31; the int -> float conversion rounds like the int64 one)
+  HSTU_DEV int bucket32(int t_q1, int t_k) const {
+    int d = t_q1 - t_k;
+    d = max(d, -d);
+    d = max(d, 1);
+    return bucket_of((float)d);
+  }
+  HSTU_DEV int bucket_of(float x) const {
     const float c = __builtin_amdgcn_logf(x) * kf;
     int bk = (int)c;
     const float fr = c - (float)bk;
@@ -329,12 +346,24 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
   char* lpos = lds;
   char* lts = lpos + (2 * n * 4 + 15) / 16 * 16;
   char* ltime = lts + ((p.num_buckets + 1) * 4 + 15) / 16 * 16;
+  char* lt32 = ltime + 8 * n;
   const int64_t* ts_row = bias_ts_row(p, b);
   for (int i = tid; i < 2 * n - 1; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = p.pos_w[i];
   if (ts_row) {
     for (int i = tid; i <= p.num_buckets; i += nthreads) *LDS_PTR(float, lts + 4 * i) = p.ts_w[i];
-    for (int i = tid; i < n; i += nthreads) *LDS_PTR(int64_t, ltime + 8 * i) = ts_row[i];
+    const int64_t t0 = ts_row[0];
+    bool big = false;
+    for (int i = tid; i < n; i += nthreads) {
+      const int64_t t = ts_row[i], o = t - t0;
+      *LDS_PTR(int64_t, ltime + 8 * i) = t;
+      *LDS_PTR(int, lt32 + 4 * i) = (int)o;
+      big = big || o >= (1LL << 30) || o <= -(1LL << 30);
+    }
+    const bool wave_big = __builtin_amdgcn_ballot_w64(big) != 0;
+    if ((tid & 63) == 0) *LDS_PTR(int, lt32 + 4 * (n + (tid >> 6))) = wave_big ? 1 : 0;
   }
+  c.lt32 = lt32;
+  c.small = false;
   c.lpos = lpos;
   c.lts = ts_row ? lts : nullptr;
   c.ltime = ts_row ? ltime : nullptr;

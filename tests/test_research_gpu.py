@@ -52,7 +52,8 @@ def test_golden_rel_bias_attention_fwd_bwd():
 
 
 @pytest.mark.parametrize("dtype,H,A,Ld,n,with_ts", [(torch.float32, 1, 50, 50, 60, True), (torch.bfloat16, 4, 64, 64, 211, True),
-                                                    (torch.float32, 2, 32, 32, 40, False), (torch.bfloat16, 2, 16, 32, 61, True)])
+                                                    (torch.float32, 2, 32, 32, 40, False), (torch.bfloat16, 2, 16, 32, 61, True),
+                                                    (torch.float32, 2, 32, 32, 90, "ms")])
 def test_rel_bias_attention_vs_oracle(dtype, H, A, Ld, n, with_ts):
     """ML-1M-like (1 head, d=50 -> padded), ML-20M-like (4 x 64, N = 211), position-only bias,
     Amazon-Books-like short sequences (N = 61, long-tail lengths)."""
@@ -65,6 +66,11 @@ def test_rel_bias_attention_vs_oracle(dtype, H, A, Ld, n, with_ts):
     off = O.complete_cumsum(lengths.astype(np.int64))
     Lt = int(off[-1])
     ts = np.sort(rng.integers(0, 10**8, size=(B, n)), axis=1).astype(np.int64)
+    if with_ts == "ms":
+        # millisecond timestamps spread over years: offsets beyond 30 bits -> the kernels' 64-bit time arithmetic
+        # (rows within 2^30 of their first timestamp take the 32-bit path); one user stays small to mix both
+        ts[1:] = ts[1:] * 40_000 + 1_600_000_000_000
+        assert (ts[1:, -1] - ts[1:, 0]).min() > 2**31
     mk = lambda d: torch.from_numpy(rng.standard_normal((Lt, H * d)) * 0.3).to(dtype)
     q, k, v = mk(A), mk(A), mk(Ld)
     g = torch.from_numpy(rng.standard_normal((Lt, H * Ld))).to(dtype)
