@@ -125,9 +125,6 @@ template <typename T> HSTU_DEV float to_f32(T x) { return (float)x; }
 //    a 4-way conflict on every transposed read.)
 template <int UPR> HSTU_DEV int swz(int r) {
   static_assert((UPR & (UPR - 1)) == 0, "UPR must be a power of two");
-#ifdef HSTU_SWZ_OLD
-  if constexpr (UPR >= 16) return r & 15; else return (r / (16 / UPR)) & (UPR - 1);
-#endif
   if constexpr (UPR >= 16) return ((r & 3) << 2) | ((r >> 2) & 3);             // 256-byte rows (or longer)
   else if constexpr (UPR == 8) return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);  // 2 rows per window: quarter = (r&1, r>>1&1)
   else return (r / (16 / UPR)) & (UPR - 1);                                     // >= 4 rows per window: quarters differ already
