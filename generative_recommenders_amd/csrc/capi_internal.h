@@ -40,7 +40,7 @@ constexpr int kLdsBudget = 160 * 1024;
 // their int32 offsets
 inline int bias_table_bytes(int max_seq_len, int num_buckets) {
   return ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16) * 16 + max_seq_len * 8 +
-         (max_seq_len * 4 + 8 * 4 + 15) / 16 * 16;   // + int32 offsets and one range flag per wave
+         ((max_seq_len + 32) * 4 + 8 * 4 + 15) / 16 * 16;   // + int32 offsets (32 padding entries) and one range flag per wave
 }
 constexpr int kDqScratchBytes = 8 * 4096;   // general backward, several key blocks: one [32 q][32 d] fp32 tile per wave
 }  // namespace hstu

@@ -294,13 +294,16 @@ struct BiasCtx {
   HSTU_DEV int64_t ts_at(int pos) const {
     return ltime ? *LDS_PTR(const int64_t, ltime + 8 * min(max(pos, 0), n - 1)) : 0;
   }
-  HSTU_DEV int t32_at(int pos) const { return *LDS_PTR(const int, lt32 + 4 * min(max(pos, 0), n - 1)); }
+  // positions 0 .. n + 31 are readable: entries >= n repeat the last timestamp (ts[N] := ts[N-1], and key / query
+  // positions of a partial tile past the sequence end, whose elements are masked anyway)
+  HSTU_DEV int t32_at(int pos) const { return *LDS_PTR(const int, lt32 + 4 * pos); }
   // after the barrier that follows stage_bias_tables: did any wave see an offset outside 30 bits?
   HSTU_DEV void finish(int nwaves) {
     small = ltime != nullptr;
-    for (int w = 0; w < nwaves; ++w) small = small && (*LDS_PTR(const int, lt32 + 4 * (n + w)) == 0);
+    for (int w = 0; w < nwaves; ++w) small = small && (*LDS_PTR(const int, lt32 + 4 * (n + 32 + w)) == 0);
   }
-  HSTU_DEV int pos_index(int qi, int key) const { return min(max(n - 1 + key - qi, 0), 2 * n - 2); }
+  // both positions are below n, so n - 1 + key - qi is a valid table index as it is
+  HSTU_DEV int pos_index(int qi, int key) const { return n - 1 + key - qi; }
   // bucket(d) = clamp((int)(logf((float)max(|d|, 1)) / div), 0, nb), exactly: the coordinate is first formed with the
   // hardware log2 (one quarter-rate instruction instead of the ~40 of logf + an IEEE divide).  Its error is below
   // 2e-5 (1 ulp of log2(x) <= 27 is 2e-6, times kf ~ 2.3, plus the rounding of the product), and the accurate
@@ -325,7 +328,7 @@ struct BiasCtx {
     int bk = (int)c;
     const float fr = c - (float)bk;
     if (fr < 1e-4f || fr > 0.9999f) bk = (int)(logf(x) / div);
-    return min(max(bk, 0), nb);
+    return min(bk, nb);   // x >= 1: never negative
   }
   HSTU_DEV float value(int pidx, int bkt) const {
     return *LDS_PTR(const float, lpos + 4 * pidx) + (lts ? *LDS_PTR(const float, lts + 4 * bkt) : 0.f);
@@ -356,8 +359,9 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
       *LDS_PTR(int, lt32 + 4 * i) = (int)o;
       big = big || o >= (1LL << 30) || o <= -(1LL << 30);
     }
+    if (tid < 32) *LDS_PTR(int, lt32 + 4 * (n + tid)) = (int)(ts_row[n - 1] - t0);   // padding: see t32_at
     const bool wave_big = __builtin_amdgcn_ballot_w64(big) != 0;
-    if ((tid & 63) == 0) *LDS_PTR(int, lt32 + 4 * (n + (tid >> 6))) = wave_big ? 1 : 0;
+    if ((tid & 63) == 0) *LDS_PTR(int, lt32 + 4 * (n + 32 + (tid >> 6))) = wave_big ? 1 : 0;
   }
   c.lt32 = lt32;
   c.small = false;
