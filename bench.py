@@ -287,6 +287,17 @@ def main():
             res["roofline_fwd"]["traffic"] = tr["fwd"]["hbm_bytes_per_launch"]
     except Exception:
         pass
+    # what a pure streaming kernel of the same read:write mix reaches on this part (tools/membench, measured separately
+    # and committed): context for `frac`, which stays relative to the 8 TB/s vendor peak
+    try:
+        mb = json.load(open(os.path.join(ROOT, "profiles", "r01_membench_2.json")))
+        best = lambda key: max(v for k, v in mb.items() if k.startswith(key + "_g"))
+        res["roofline"]["streaming_4r3w_GBps"] = best("r4w3")
+        res["roofline"]["frac_of_streaming_4r3w"] = att["bwd_gbps"] / best("r4w3")
+        res["roofline_fwd"]["streaming_3r1w_GBps"] = best("r3w1")
+        res["roofline_fwd"]["frac_of_streaming_3r1w"] = att["fwd_gbps"] / best("r3w1")
+    except Exception:
+        pass
     if rank == 0:
         try:
             res["measured_copy_GBps"] = copy_bandwidth(device)
