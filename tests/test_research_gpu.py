@@ -53,7 +53,12 @@ def test_golden_rel_bias_attention_fwd_bwd():
 
 @pytest.mark.parametrize("dtype,H,A,Ld,n,with_ts", [(torch.float32, 1, 50, 50, 60, True), (torch.bfloat16, 4, 64, 64, 211, True),
                                                     (torch.float32, 2, 32, 32, 40, False), (torch.bfloat16, 2, 16, 32, 61, True),
-                                                    (torch.float32, 2, 32, 32, 90, "ms")])
+                                                    (torch.float32, 2, 32, 32, 90, "ms"),
+                                                    # LDS-tight shapes: 128-wide heads at N = 200 (the K/V block fills the
+                                                    # LDS: fewer privatised histogram copies) and N = 420 (several key
+                                                    # blocks: fp32 dq accumulation + bias histograms together)
+                                                    (torch.bfloat16, 2, 128, 128, 200, True), (torch.bfloat16, 1, 128, 128, 420, True),
+                                                    (torch.float32, 1, 64, 64, 300, True)])
 def test_rel_bias_attention_vs_oracle(dtype, H, A, Ld, n, with_ts):
     """ML-1M-like (1 head, d=50 -> padded), ML-20M-like (4 x 64, N = 211), position-only bias,
     Amazon-Books-like short sequences (N = 61, long-tail lengths)."""
