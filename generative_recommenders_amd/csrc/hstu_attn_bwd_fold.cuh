@@ -132,13 +132,24 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
 #pragma unroll
   for (int h8 = 0; h8 < 2; ++h8) {
     float pv[8], dsv[8];
+    {   // two elements per VALU instruction where the ISA has a packed fp32 form (mul / add / fma): -1.6 % kernel time
+      const f32x2 a2 = {p.alpha, p.alpha};
+      const f32x2 c2 = {-1.44269504088896340736f * p.alpha, -1.44269504088896340736f * p.alpha};
+      const f32x2 one2 = {1.f, 1.f};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = 8 * h8 + j;
-      const float x = s[r] * p.alpha;
-      const float sg = fast_sigmoid(x);
-      pv[j] = x * sg;
-      dsv[j] = dp[r] * sg * (1.f + x * (1.f - sg));
+      for (int j = 0; j < 8; j += 2) {
+        const int r = 8 * h8 + j;
+        const f32x2 sv = {s[r], s[r + 1]}, dpv = {dp[r], dp[r + 1]};
+        const f32x2 x = sv * a2, t = sv * c2;
+        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        const f32x2 dn = e + one2;
+        const f32x2 sg = {__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])};
+        const f32x2 pr = x * sg;
+        const f32x2 w = x * (one2 - sg) + one2;     // 1 + x (1 - sg)
+        const f32x2 dsr = dpv * sg * w;
+        pv[j] = pr[0]; pv[j + 1] = pr[1];
+        dsv[j] = dsr[0]; dsv[j + 1] = dsr[1];
+      }
     }
     if (mode == 1) {
       // plain causal: keep (key <= qi) & (qi < len) (then key < len too).  Integer arithmetic only: compares would
