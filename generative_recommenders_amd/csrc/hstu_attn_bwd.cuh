@@ -364,19 +364,32 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
       for (int h8 = 0; h8 < 2; ++h8) {
         float pv[8], dsv[8];
         int pidx[8], bkt[8];
+        float xb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int r = 8 * h8 + j;
-          float x = s[r] * p.alpha;
+          xb[j] = 0.f;
           if constexpr (BIAS) {
+            const int r = 8 * h8 + j;
             const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             pidx[j] = bc.pos_index(qi, key);
             bkt[j] = bc.small ? bc.bucket32(bc.t32_at(qi + 1), t_k32) : bc.bucket(bc.ts_at(qi + 1), t_k);   // wave-uniform choice
-            x += bc.value(pidx[j], bkt[j]);
+            xb[j] = bc.value(pidx[j], bkt[j]);
           }
-          const float sg = fast_sigmoid(x);
-          pv[j] = x * sg;
-          dsv[j] = dp[r] * sg * (1.f + x * (1.f - sg));
+        }
+        {   // two elements per VALU instruction where the ISA has a packed fp32 form (mul / add / fma)
+          const f32x2 a2 = {p.alpha, p.alpha}, one2 = {1.f, 1.f}, nl2 = {-1.44269504088896340736f, -1.44269504088896340736f};
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const int r = 8 * h8 + j;
+            const f32x2 sv = {s[r], s[r + 1]}, dpv = {dp[r], dp[r + 1]}, bv = {xb[j], xb[j + 1]};
+            const f32x2 x = sv * a2 + bv, t = x * nl2;
+            const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            const f32x2 dn = e + one2;
+            const f32x2 sg = {__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])};
+            const f32x2 pr = x * sg, w = x * (one2 - sg) + one2, dsr = dpv * sg * w;
+            pv[j] = pr[0]; pv[j + 1] = pr[1];
+            dsv[j] = dsr[0]; dsv[j + 1] = dsr[1];
+          }
         }
         if (mode == 1) {          // plain causal, no targets: key <= query (and both in range)
 #pragma unroll
