@@ -39,8 +39,8 @@ constexpr int kLdsBudget = 160 * 1024;
 // bytes of the bias tables a workgroup stages in LDS: pos_w (2N-1 floats), ts_w (nb+1 floats), N int64 timestamps,
 // their int32 offsets
 inline int bias_table_bytes(int max_seq_len, int num_buckets) {
-  return ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16) * 16 + max_seq_len * 8 +
-         ((max_seq_len + 32) * 4 + 8 * 4 + 15) / 16 * 16;   // + int32 offsets (32 padding entries) and one range flag per wave
+  return ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16 + (max_seq_len * 8 + 15) / 16) * 16 +
+         (2 * ((max_seq_len + 32 + 3) / 4 * 4) * 4 + 8 * 4 + 15) / 16 * 16;   // + int32 offsets and their copy shifted by one (padded), one range flag per wave
 }
 constexpr int kDqScratchBytes = 8 * 4096;   // general backward, several key blocks: one [32 q][32 d] fp32 tile per wave
 }  // namespace hstu

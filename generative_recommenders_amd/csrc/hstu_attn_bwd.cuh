@@ -365,6 +365,17 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         float pv[8], dsv[8];
         int pidx[8], bkt[8];
         float xb[8];
+        int tq4[8];
+        if constexpr (BIAS) {
+          if (bc.small) {   // next-item timestamps of the 4 consecutive query rows of a register group: one 16-byte LDS read
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const auto t4 = bc.t32x4_next(i0 + 8 * (2 * h8 + g) + 4 * hf);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) tq4[4 * g + j] = t4[j];
+            }
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           xb[j] = 0.f;
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
             const int r = 8 * h8 + j;
             const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             pidx[j] = bc.pos_index(qi, key);
-            bkt[j] = bc.small ? bc.bucket32(bc.t32_at(qi + 1), t_k32) : bc.bucket(bc.ts_at(qi + 1), t_k);   // wave-uniform choice
+            bkt[j] = bc.small ? bc.bucket32(tq4[j], t_k32) : bc.bucket(bc.ts_at(qi + 1), t_k);   // wave-uniform choice
             xb[j] = bc.value(pidx[j], bkt[j]);
           }
         }

@@ -288,7 +288,7 @@ struct BiasCtx {
   const char* lts;     // LDS: ts_w, nb+1 floats, or nullptr (position-only bias)
   const char* ltime;   // LDS: this user's n timestamps (int64), or nullptr
   const char* lt32;    // LDS: the same as int32 offsets from the row's first timestamp, then one "out of range" word per wave
-  int n, nb;
+  int n, nb, npad;     // npad = n + 32 rounded up to a multiple of 4: length of each int32 array
   bool small;          // every offset fits 30 bits: time differences are formed and converted in 32-bit arithmetic
   float div, kf;       // kf = ln 2 / div: bucket coordinate = log2(d) * kf
   HSTU_DEV int64_t ts_at(int pos) const {
@@ -297,10 +297,15 @@ struct BiasCtx {
   // positions 0 .. n + 31 are readable: entries >= n repeat the last timestamp (ts[N] := ts[N-1], and key / query
   // positions of a partial tile past the sequence end, whose elements are masked anyway)
   HSTU_DEV int t32_at(int pos) const { return *LDS_PTR(const int, lt32 + 4 * pos); }
+  // four consecutive entries in one 16-byte read: offsets of positions pos .. pos+3 (pos a multiple of 4), and of the
+  // positions FOLLOWING them (the query side uses the next item's timestamp) from a copy shifted by one
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  HSTU_DEV i32x4 t32x4_at(int pos) const { return *LDS_PTR(const i32x4, lt32 + 4 * pos); }
+  HSTU_DEV i32x4 t32x4_next(int pos) const { return *LDS_PTR(const i32x4, lt32 + 4 * (npad + pos)); }
   // after the barrier that follows stage_bias_tables: did any wave see an offset outside 30 bits?
   HSTU_DEV void finish(int nwaves) {
     small = ltime != nullptr;
-    for (int w = 0; w < nwaves; ++w) small = small && (*LDS_PTR(const int, lt32 + 4 * (n + 32 + w)) == 0);
+    for (int w = 0; w < nwaves; ++w) small = small && (*LDS_PTR(const int, lt32 + 4 * (2 * npad + w)) == 0);
   }
   // both positions are below n, so n - 1 + key - qi is a valid table index as it is
   HSTU_DEV int pos_index(int qi, int key) const { return n - 1 + key - qi; }
@@ -346,7 +351,7 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
   char* lpos = lds;
   char* lts = lpos + (2 * n * 4 + 15) / 16 * 16;
   char* ltime = lts + ((p.num_buckets + 1) * 4 + 15) / 16 * 16;
-  char* lt32 = ltime + 8 * n;
+  char* lt32 = ltime + (8 * n + 15) / 16 * 16;
   const int64_t* ts_row = bias_ts_row(p, b);
   for (int i = tid; i < 2 * n - 1; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = p.pos_w[i];
   if (ts_row) {
@@ -359,11 +364,16 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
       *LDS_PTR(int, lt32 + 4 * i) = (int)o;
       big = big || o >= (1LL << 30) || o <= -(1LL << 30);
     }
-    if (tid < 32) *LDS_PTR(int, lt32 + 4 * (n + tid)) = (int)(ts_row[n - 1] - t0);   // padding: see t32_at
+    const int npad = (n + 32 + 3) / 4 * 4;
+    const int last = (int)(ts_row[n - 1] - t0);
+    for (int i = n + tid; i < npad; i += nthreads) *LDS_PTR(int, lt32 + 4 * i) = last;          // padding: see t32_at
+    for (int i = tid; i < npad; i += nthreads)                                                  // shifted copy: entry i = t[i+1]
+      *LDS_PTR(int, lt32 + 4 * (npad + i)) = i + 1 < n ? (int)(ts_row[i + 1] - t0) : last;
     const bool wave_big = __builtin_amdgcn_ballot_w64(big) != 0;
-    if ((tid & 63) == 0) *LDS_PTR(int, lt32 + 4 * (n + 32 + (tid >> 6))) = wave_big ? 1 : 0;
+    if ((tid & 63) == 0) *LDS_PTR(int, lt32 + 4 * (2 * npad + (tid >> 6))) = wave_big ? 1 : 0;
   }
   c.lt32 = lt32;
+  c.npad = (n + 32 + 3) / 4 * 4;
   c.small = false;
   c.lpos = lpos;
   c.lts = ts_row ? lts : nullptr;
