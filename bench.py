@@ -240,8 +240,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HSTU ops are HIP kernels with no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # (== local_rank on a node with one GPU per rank)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     _lib.lib()
 
     att = attention_section(args, rank, world, device)

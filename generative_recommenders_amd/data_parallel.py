@@ -29,7 +29,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # HSTU_DIST_BACKEND=gloo: rehearse the multi-rank flow where there are fewer GPUs than ranks (RCCL refuses two
+            # ranks on one device; gloo moves the few control tensors through the host)
+            backend = os.environ.get("HSTU_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)      # RCCL binds a communicator to the device current at first use
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
