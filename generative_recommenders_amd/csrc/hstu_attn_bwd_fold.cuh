@@ -385,7 +385,9 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   const int uh = blockIdx.x;
   const int b = uh / p.heads, hd = uh % p.heads;
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
-  const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
+  // A user longer than max_seq_len is a caller error (the reference's padded path would truncate it to N rows); the
+  // kernel stays inside its 7 K/V slots: rows past 32 * tmax are ignored (their gradient rows are not written).
+  const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), 32 * tmax);
   if (len <= 0) return;
   const MaskCtx mc = make_mask_ctx(p, b, len);
   HSTU_TRACE_DECL(bp.workspace, bp.workspace != nullptr && blockIdx.x == 4096);

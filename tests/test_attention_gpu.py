@@ -481,3 +481,32 @@ def test_graph_capture_and_replay():
         want = [want_o, dq.clone(), dk.clone(), dv.clone()]
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+
+
+def test_user_longer_than_max_seq_len_does_not_disturb_the_others():
+    """lengths above max_seq_len are a caller error; the kernels must stay inside their buffers and the other users of
+    the batch must get exactly what they get alone (the folded backward keeps a user's whole K/V block in 7 LDS slots)."""
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    N, H, d = 200, 2, 64
+    lengths = torch.tensor([150, 260, 200, 37], device=DEV)          # user 1 is too long
+    off = torch.zeros(5, dtype=torch.int64, device=DEV)
+    off[1:] = torch.cumsum(lengths, 0)
+    L = int(off[-1])
+    q, k, v, g = (torch.empty(L, H, d, device=DEV, dtype=torch.bfloat16).uniform_(-0.3, 0.3, generator=gen) for _ in range(4))
+    outs = {}
+    for name, users in (("all", [0, 1, 2, 3]), ("ok", [0, 2, 3])):
+        rows = torch.cat([torch.arange(int(off[u]), int(off[u + 1]), device=DEV) for u in users])
+        lo = torch.zeros(len(users) + 1, dtype=torch.int64, device=DEV)
+        lo[1:] = torch.cumsum(lengths[users], 0)
+        qq, kk, vv = (t[rows].clone().requires_grad_() for t in (q, k, v))
+        o = _ops().hstu_mha(N, 0.125, qq, kk, vv, lo)
+        o.backward(g[rows])
+        torch.cuda.synchronize()
+        per = {}
+        for i, u in enumerate(users):
+            s, e = int(lo[i]), int(lo[i + 1])
+            per[u] = [t[s:e].clone() for t in (o, qq.grad, kk.grad, vv.grad)]
+        outs[name] = per
+    for u in (0, 2, 3):
+        for a, b in zip(outs["all"][u], outs["ok"][u]):
+            assert torch.equal(a, b)
