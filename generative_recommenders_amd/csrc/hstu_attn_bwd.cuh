@@ -377,13 +377,23 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          xb[j] = 0.f;
-          if constexpr (BIAS) {
+        for (int j = 0; j < 8; ++j) xb[j] = 0.f;
+        if constexpr (BIAS) {
+          if (bc.small) {   // (workgroup-uniform: one branch per half tile, not one per element)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bkt[j] = bc.bucket32(tq4[j], t_k32);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int r = 8 * h8 + j;
+              bkt[j] = bc.bucket(bc.ts_at(i0 + (r & 3) + 8 * (r >> 2) + 4 * hf + 1), t_k);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
             const int r = 8 * h8 + j;
             const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             pidx[j] = bc.pos_index(qi, key);
-            bkt[j] = bc.small ? bc.bucket32(tq4[j], t_k32) : bc.bucket(bc.ts_at(qi + 1), t_k);   // wave-uniform choice
             xb[j] = bc.value(pidx[j], bkt[j]);
           }
         }
