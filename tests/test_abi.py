@@ -211,3 +211,28 @@ def test_negatives_samplers_contract_and_no_cpu_path():
     loss = SS.SampledSoftmaxLoss(num_to_sample=4, softmax_temperature=0.05)
     with pytest.raises(RuntimeError, match="GPU"):
         loss.jagged_forward(torch.randn(3, 8), torch.tensor([1, 2, 3]), torch.randn(3, 8), torch.ones(3), s)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/hstu_hip.h is the FFI contract: it must compile as strict C99 (cgo / JNI / N-API style bindings parse
+    it as C) and a C program must link against the library and call it (no GPU needed for hstu_abi_version)."""
+    import shutil
+    import subprocess
+    from generative_recommenders_amd import _lib
+
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("gcc or the built library is not available")
+    src = tmp_path / "abi_c_check.c"
+    src.write_text('#include <stdio.h>\n#include "hstu_hip.h"\n'
+                   "int main(void) {\n  HstuAttnParams p; HstuAttnBwdParams bp; (void)p; (void)bp;\n"
+                   '  printf("%d\\n", hstu_abi_version());\n  return hstu_abi_version() == HSTU_ABI_VERSION ? 0 : 1;\n}\n')
+    exe = tmp_path / "abi_c_check"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                        str(exe), "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and out.stdout.strip() == str(_lib.ABI_VERSION), (out.stdout, out.stderr)
