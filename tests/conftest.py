@@ -35,3 +35,15 @@ def scalar(x):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_torch_rng(request):
+    """Every test starts from the same torch generator state (CPU and, when present, GPU): a few tests draw inputs
+    or module initialisations from the global generator, and a tolerance check must not depend on the draw of the day."""
+    import zlib
+
+    import torch
+
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+    yield

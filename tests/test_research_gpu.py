@@ -63,6 +63,7 @@ def test_rel_bias_attention_vs_oracle(dtype, H, A, Ld, n, with_ts):
     """ML-1M-like (1 head, d=50 -> padded), ML-20M-like (4 x 64, N = 211), position-only bias,
     Amazon-Books-like short sequences (N = 61, long-tail lengths)."""
     m = _mods()
+    torch.manual_seed(n + H)                           # module initialisation draws from torch's generator: fix it
     rng = np.random.default_rng(n + H)
     B = 6
     lengths = rng.integers(1, n + 1, size=B)
