@@ -24,6 +24,11 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   if (!enabled) return false;
   if (p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.contextual_seq_len > 0) return false;
   if (p.dqk != p.dv || (p.dqk != 128 && p.dqk != 64)) return false;
+  // masked elements start their S accumulator at -1e30 (hstu_attn_bwd_fold.cuh, fold_pair): alpha * 1e30 must stay
+  // finite and alpha * 1.44e30 must overflow exp2; alpha == 0 is fine (every product with a masked element is then
+  // multiplied by alpha = 0 or by silu(0) = 0 anyway)
+  const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;
+  if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 

@@ -34,6 +34,14 @@
 #define FOLD_SDP_AHEAD 3   // MFMAs whose LDS operands are requested ahead in the S / dP stream
 #endif
 
+#ifndef FOLD_ABLATE
+#define FOLD_ABLATE 0      // timing experiments only (WRONG results; tools/ab_bwd.py): 1 no dQ stores, 2 no dk/dv
+#endif                     // stores, 4 no stage DMA after step 0, 8 no tail, 16 no K/V DMA, 32 no dQ GEMM, 64 no pairs,
+                           // 128 / 256 every problem aliases one of the first 256 / 32 (Infinity-Cache / L2 resident data)
+#ifndef FOLD_PERSIST
+#define FOLD_PERSIST 2     // 0: one workgroup per (user, head); 1: one workgroup per CU walks the problems; 2: and issues the
+#endif                     // next problem's K/V tiles of the slots its own tail does not use
+
 namespace hstu {
 
 template <typename T, int DQK, int DV>
@@ -84,7 +92,7 @@ HSTU_DEV int fold_ds_off(int row, int chunk) { return (row << 6) + ((chunk ^ ((r
 template <typename T, int DQK, int DV>
 HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* __restrict__ Kw, const char* __restrict__ Vw,
                         const char* __restrict__ Qs, const char* __restrict__ dOs, char* __restrict__ myds, int i0, int k0, f32x16 (&dk_acc)[DQK / 32],
-                        f32x16 (&dv_acc)[DV / 32], int lane HSTU_TRACE_ARG) {
+                        f32x16 (&dv_acc)[DV / 32], int lane, int dmvm HSTU_TRACE_ARG) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -93,8 +101,45 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
   const int key = k0 + n32;
   const bool key_ok = key < len;
   f32x16 s, dp;
+  // C layout of S / dP: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf.  Query rows >= len hold a
+  // clamped copy of a real row (LDS-DMA cannot zero-fill), so only tiles entirely inside the sequence need no mask.
+  Frag pb[2], dsb[2];
+  int mode;   // wave-uniform: 0 = no mask needed, 1 = plain causal, 2 = general mask algebra
+  if (mc.simple) mode = (k0 < i0 && i0 + 32 <= len) ? 0 : 1;    // strictly below the diagonal and all rows real
+  else mode = (i0 + 32 <= len && mc.pair_fully_valid(i0, 32, k0, 32)) ? 0 : 2;
+  const int key_id = mc.id_of(key);
+  const int key_bits = key_ok ? -1 : 0;
+  // The mask of a pair is 16 bits per lane (bit r = register r survives) and it is applied by
+  // STARTING the S accumulator of a masked element at -1e30 instead of 0: then x = alpha S is hugely negative,
+  // exp2(-x log2 e) = +inf, sigmoid = 1/inf = 0 exactly, and P' = x * 0 = -0, dS' = dP * 0 * (x + 1) = +-0 -- the
+  // element-wise block needs no mask code at all, is the same for every pair and is ONE basic block (which is what
+  // lets the scheduler weave it into the MFMAs).  Two instructions per element (bit-field extract, AND) in place of
+  // the accumulator's v_mov 0.  Needs 1e-28 < |alpha| < 3e8 (alpha = 0 zeroes dq, dk and P' by itself); the
+  // dispatcher sends anything else to the general kernel.
+  // Plain causal: the pattern depends on the pair only through two wave-uniform facts -- is this the diagonal tile
+  // (keep key <= query) and is it the sequence's last, partial query tile (keep query < len; every key of an earlier
+  // tile is then < len too) -- both patterns live in one lane-constant register of the kernel (dmvm).  Any other
+  // mask: the bits are collected from the general predicate.
+  {
+    int km = -1;
+    if (mode == 1) km = ((k0 == i0) ? dmvm : -1) & ((i0 + 32 > len) ? (dmvm >> 16) : -1);
+    if (mode == 2) {
+      km = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) {
+        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        km |= (mc.keep_bits_noctx(qi, key, key_id) & key_bits & 1) << r;
+      }
+    }
+    const unsigned nk = ~(unsigned)km;
+    const unsigned neg = __builtin_bit_cast(unsigned, p.alpha < 0.f ? 1e30f : -1e30f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = ((int)(nk << (31 - r))) >> 31;        // all ones iff masked
+      s[r] = __builtin_bit_cast(float, (unsigned)m & neg);
+      dp[r] = 0.f;
+    }
+  }
   // S and dP as ONE stream of 16 MFMAs alternating between the two accumulators (no back-to-back dependency), with
   // the LDS reads of item m + AHEAD issued before the MFMA of item m.  The order is pinned with scheduling
   // barriers: left alone, hipcc emits read, read, wait, MFMA per item into the same registers, i.e. one full LDS
@@ -120,17 +165,7 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
     }
   }
   HSTU_MARK(11);
-  // C layout: column n32 = key, register r = query row (r&3) + 8 (r>>2) + 4 hf.  Query rows >= len
-  // hold a clamped copy of a real row (LDS-DMA cannot zero-fill), so only tiles entirely inside the
-  // sequence may skip the per-element mask.
-  Frag pb[2], dsb[2];
-  int mode;   // wave-uniform: 0 = no mask needed, 1 = plain causal, 2 = general mask algebra
-  if (mc.simple) mode = (k0 < i0 && i0 + 32 <= len) ? 0 : 1;    // strictly below the diagonal and all rows real
-  else mode = (i0 + 32 <= len && mc.pair_fully_valid(i0, 32, k0, 32)) ? 0 : 2;
-  const int key_id = mc.id_of(key);
-  const int key_bits = key_ok ? -1 : 0;
-#pragma unroll
-  for (int h8 = 0; h8 < 2; ++h8) {
+  auto elem = [&](const int h8) {
     float pv[8], dsv[8];
     {   // two elements per VALU instruction where the ISA has a packed fp32 form (mul / add / fma): -1.6 % kernel time
       const f32x2 a2 = {p.alpha, p.alpha};
@@ -151,31 +186,11 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
         dsv[j] = dsr[0]; dsv[j + 1] = dsr[1];
       }
     }
-    if (mode == 1) {
-      // plain causal: keep (key <= qi) & (qi < len) (then key < len too).  Integer arithmetic only: compares would
-      // go through SGPR pairs and the scalar unit, a VALU -> SALU -> VALU round trip per element.
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * h8 + j;
-        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-        const int q_eff = qi | ((len - 1 - qi) >> 31);          // qi, or -1 when qi >= len
-        const int keep = (key - 1 - q_eff) >> 31;                // all ones iff key <= q_eff
-        pv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, pv[j]) & keep);
-        dsv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, dsv[j]) & keep);
-      }
-    } else if (mode == 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * h8 + j;
-        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-        const int keep = mc.keep_bits_noctx(qi, key, key_id) & key_bits;
-        pv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, pv[j]) & keep);
-        dsv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, dsv[j]) & keep);
-      }
-    }
     pb[h8] = E::pack8(pv);
     dsb[h8] = E::pack8(dsv);
-  }
+  };
+  elem(0);
+  elem(1);
   HSTU_MARK(12);
   // dV_w^T[dv][key] += dO_i^T[dv][q] P'[q][key]   and   dK_w^T[d][key] += Q_i^T[d][q] dS'[q][key]:
   // one stream of 16 MFMAs alternating between the dV and dK accumulators, A fragments (transposed LDS reads of
@@ -234,7 +249,7 @@ HSTU_DEV void fold_copy_out(const char* __restrict__ tile, char* gtile, int64_t 
   for (int u = tid; u < 32 * UPR; u += kBwdThreads) {
     const int row = u / UPR, unit = u % UPR;
     const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, unit));
-    if (row < rows_valid) gstore16(gtile + row * row_stride_bytes + unit * 16, v);
+    if (row < rows_valid && (!(FOLD_ABLATE & 2) || row_stride_bytes == -12345)) gstore16(gtile + row * row_stride_bytes + unit * 16, v);
   }
 }
 
@@ -359,7 +374,7 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   for (int sd = 0; sd < 2; ++sd) {
     if (sd == 1 && !b_on) break;
     const int qrow = 32 * (sd ? bq : a) + 16 * qb + i16;
-    if (qrow < mc.len) {
+    if (qrow < mc.len && (!(FOLD_ABLATE & 1) || bp.total_rows == -12345)) {
       char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
       u32x4 v = {E::pk2(acc[sd][0][0] * ds_scale, acc[sd][0][1] * ds_scale), E::pk2(acc[sd][0][2] * ds_scale, acc[sd][0][3] * ds_scale),
                  E::pk2(acc[sd][1][0] * ds_scale, acc[sd][1][1] * ds_scale), E::pk2(acc[sd][1][2] * ds_scale, acc[sd][1][3] * ds_scale)};
@@ -368,29 +383,31 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   }
 }
 
+// One (user, head) problem `uh` of `total`, on the calling workgroup (all of its LDS).
 template <typename T, int DQK, int DV>
-__global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void hstu_attn_bwd_fold_kernel(const HstuAttnBwdParams bp, int tmax) {
+HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int total, char* smem, int tid, int lane, int wave,
+                          int uh_next, int& pre_lo) {
   using C = BwdCfg<T, DQK, DV>;
   using F = FoldCfg<T, DQK, DV>;
   static_assert(C::EB == 2, "the folded backward is built for 16-bit I/O");
   static_assert(DQK / 32 <= 4, "dQ GEMM: 32 feature columns x 16 query rows per wave");
   static_assert(DQK == DV, "hand-over regions assume equal K and V tile sizes");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const HstuAttnParams& p = bp.fwd;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int uh = blockIdx.x;
-  const int b = uh / p.heads, hd = uh % p.heads;
+  const int b = ((FOLD_ABLATE & 128) ? uh % 256 : (FOLD_ABLATE & 256) ? uh % 32 : uh) / p.heads, hd = uh % p.heads;   // 128 / 256: every problem aliases one of the first 256 / 32 (cache-resident data)
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
   // A user longer than max_seq_len is a caller error (the reference's padded path would truncate it to N rows); the
   // kernel stays inside its 7 K/V slots: rows past 32 * tmax are ignored (their gradient rows are not written).
   const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), 32 * tmax);
+  const int pre_in = pre_lo;             // K/V tiles >= pre_in of THIS problem were issued by the previous problem's tail
+  pre_lo = F::kMaxTiles;
   if (len <= 0) return;
+  // the problem this workgroup takes next (persistent launch): its offsets are loaded now, its K/V tiles of the slots
+  // that are free during this problem's tail are issued there
+  const int b3 = uh_next >= 0 ? uh_next / p.heads : b, hd3 = uh_next >= 0 ? uh_next % p.heads : 0;
+  const int64_t off3 = uh_next >= 0 ? load_index(p.seq_offsets, b3, p.offsets_dtype) : 0;
+  const int len3 = uh_next >= 0 ? min((int)(load_index(p.seq_offsets, b3 + 1, p.offsets_dtype) - off3), 32 * tmax) : 0;
   const MaskCtx mc = make_mask_ctx(p, b, len);
-  HSTU_TRACE_DECL(bp.workspace, bp.workspace != nullptr && blockIdx.x == 4096);
+  HSTU_TRACE_DECL(bp.workspace, bp.workspace != nullptr && uh == 4096);
   HSTU_MARK(1);
 
   const int nt = (len + 31) >> 5;        // tiles of this user (<= tmax <= 7)
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   };
 
   // ---- prologue: the whole K/V block and the first two query tiles, all by LDS-DMA
-  for (int t = 0; t < nt; ++t) {
+  for (int t = 0; t < ((FOLD_ABLATE & 16) ? 0 : min(nt, pre_in)); ++t) {
     char* dst = smem + t * C::PAIR;
     fold_tile_dma<T, DQK>(dst, kbase, k_rs, 32 * t, len, wave, lane);
     fold_tile_dma<T, DV>(dst + C::KT, vbase, v_rs, 32 * t, len, wave, lane);
@@ -443,6 +460,19 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     for (int r = 0; r < 16; ++r) dv_acc[d][r] = 0.f;
   const float ds_scale = p.scale * p.alpha;
 
+  // lane-constant mask patterns of the plain-causal case (see fold_pair): low half = diagonal tile, bit r set iff
+  // key n32 <= query row (r&3) + 8 (r>>2) + 4 hf; high half = last query tile, bit r set iff that row is < len
+  int dmvm = 0;
+  {
+    const int n32 = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+      dmvm |= (n32 <= row ? 1 : 0) << r;
+      dmvm |= (32 * (nt - 1) + row < len ? 1 : 0) << (16 + r);
+    }
+  }
+
   for (int k = 0; k < ns; ++k) {
     const int a = nt - 1 - k, bq = k;
     const bool b_on = bq < a;
@@ -465,7 +495,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     const char* st = stageA;
     if (wave <= a) { kt = wave; qt = a; }
     else if (b_on && kBwdWaves - 1 - wave <= bq) { kt = kBwdWaves - 1 - wave; qt = bq; st = stageB; }
-    if (kt >= 0 && (mc.win == 0 || mc.pair_may_be_active(32 * qt, 32, 32 * kt, 32))) {
+    if (kt >= 0 && !(FOLD_ABLATE & 64) && (mc.win == 0 || mc.pair_may_be_active(32 * qt, 32, 32 * kt, 32))) {
       const char* Kw = smem + kt * C::PAIR;
       // (the lane id is laundered per phase: LDS offsets derived from it are then recomputed where they are used --
       // a few dozen VALU instructions -- instead of being hoisted out of the step loop, where some 60 of them,
@@ -473,13 +503,13 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
       int lane1 = lane;
       asm volatile("" : "+v"(lane1));
       fold_pair<T, DQK, DV>(p, mc, Kw, Kw + C::KT, st, st + C::KT, dsbuf + wave * F::DSB, 32 * qt, 32 * kt, dk_acc,
-                            dv_acc, lane1 HSTU_TRACE_PASS);
+                            dv_acc, lane1, dmvm HSTU_TRACE_PASS);
     }
     HSTU_MARK(13);
     HSTU_MARK(14);
     __syncthreads();   // dS' of this step published; stage reads done
     HSTU_MARK(15);
-    if (k + 1 < ns) stage_dma(a - 1, bq + 1, bq + 1 < a - 1);
+    if (k + 1 < ns && !(FOLD_ABLATE & 4)) stage_dma(a - 1, bq + 1, bq + 1 < a - 1);
     if (k > 0) {   // dk / dv of the previous step's diagonal key tile (parked in K/V slot a + 1): out, by all waves
       const int kt1 = a + 1;
       fold_copy_out<T, DQK>(smem + kt1 * C::PAIR, dk_head + (int64_t)(32 * kt1) * dk_rs, dk_rs, len - 32 * kt1, tid);
@@ -489,7 +519,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // ---- phase 2: dQ of the two query tiles, 16 feature columns per wave
     int lane2 = lane;
     asm volatile("" : "+v"(lane2));
-    fold_dq_phase<T, DQK, DV>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
+    if (!(FOLD_ABLATE & 32)) fold_dq_phase<T, DQK, DV>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
     HSTU_MARK(17);
     if (kt == wave && wave == a) {
       // diagonal step of side A: no later query tile reaches key tile `wave`, its dK/dV are final (a >= nt/2 in
@@ -507,6 +537,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     HSTU_MARK(23);
   }
   HSTU_MARK(20);
+  if (FOLD_ABLATE & 8) return;
   // ---- tail.  Key tiles 0..nb-1 have two partial sums: side A (wave t) and side B (wave 7 - t).  Each of the two
   // waves finishes HALF of the tile: the side-A owner hands its dV partial over and finishes dK, the side-B owner
   // hands its dK partial over and finishes dV.  Hand-over regions (fp32, lane-linear, one K/V slot's size each):
@@ -520,6 +551,19 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   char* const reg_a = smem + tb * C::PAIR;
   char* const reg_b = tb == 0 ? stageA : (tb == 1 ? stageB : dsbuf);
   __syncthreads();     // K/V tiles, stages and dS' buffers are dead from here on
+  if (len3 > 0) {
+    // K/V slots above the last step's diagonal tile are not touched by the tail: the next problem's tiles of those
+    // slots stream in under it
+    const char* kb3 = (const char*)p.k + (off3 * p.k_row_stride + (int64_t)hd3 * p.k_head_stride) * C::EB;
+    const char* vb3 = (const char*)p.v + (off3 * p.v_row_stride + (int64_t)hd3 * p.v_head_stride) * C::EB;
+    const int nt3 = (len3 + 31) >> 5;
+    for (int t = a_last + 1; t < nt3; ++t) {
+      char* dst = smem + t * C::PAIR;
+      fold_tile_dma<T, DQK>(dst, kb3, k_rs, 32 * t, len3, wave, lane);
+      fold_tile_dma<T, DV>(dst + C::KT, vb3, v_rs, 32 * t, len3, wave, lane);
+    }
+    pre_lo = a_last + 1;
+  }
   int lane4 = lane;
   asm volatile("" : "+v"(lane4));
   if (wave == a_last) fold_park_tile<T, DQK>(dk_acc, ds_scale, smem + wave * C::PAIR, lane4);
@@ -545,6 +589,30 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     fold_copy_out<T, DV>(smem + t * C::PAIR + C::KT, dv_head + (int64_t)(32 * t) * dv_rs, dv_rs, len - 32 * t, tid);
   }
   HSTU_MARK(21);
+}
+
+// FOLD_PERSIST: one workgroup per CU walks the problems blockIdx.x, blockIdx.x + gridDim.x, ... (no workgroup
+// relaunch between two problems of a CU: the dispatch gap, the kernel-argument loads and the wave start-up are paid once)
+template <typename T, int DQK, int DV>
+__global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void hstu_attn_bwd_fold_kernel(const HstuAttnBwdParams bp, int tmax) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = bp.fwd.batch * bp.fwd.heads;
+  if (FOLD_PERSIST) {
+    int pre_lo = 7;
+    for (int uh = blockIdx.x; uh < total; uh += gridDim.x) {
+      int uh_l = uh;
+      asm volatile("" : "+s"(uh_l));     // nothing of problem i+1 is hoisted into problem i
+      const int uh_n = (FOLD_PERSIST >= 2 && uh_l + (int)gridDim.x < total) ? uh_l + (int)gridDim.x : -1;
+      fold_problem<T, DQK, DV>(bp, tmax, uh_l, total, smem, tid, lane, wave, uh_n, pre_lo);
+      __syncthreads();                   // the tail's LDS reads are done before the next prologue's DMA lands
+    }
+  } else {
+    int pre_lo = 7;
+    fold_problem<T, DQK, DV>(bp, tmax, blockIdx.x, total, smem, tid, lane, wave, -1, pre_lo);
+  }
 }
 
 }  // namespace hstu

@@ -42,31 +42,25 @@ def dump(t, names, waves):
             print(f"  {str(names.get(tag, tag)):>18s}  t={ts - t0:8d}  (+{ts - prev})")
             prev = ts
 
-ftrace = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
-L.lib()
-import ctypes
-tl = ctypes.CDLL(L.LIB_PATH)
-tl.hstu_trace_set_fwd.argtypes = [ctypes.c_void_p]
-print("set fwd trace:", tl.hstu_trace_set_fwd(ftrace.data_ptr()))
-for _ in range(3):
-    _launch.attn_fwd(q, k, v, off, None, N, d ** -0.5, 1.0 / N)
-torch.cuda.synchronize()
-print("===== FORWARD (workgroup 4096)")
-dump(ftrace.cpu().view(8, 128, 2).numpy(), {1: "start", 2: "Q issued+done", 3: "tile0 staged", 10: "iter top (loads issued)",
-     11: "S done", 12: "elementwise done", 13: "PV done", 14: "next tile written", 15: "barrier passed", 20: "loop done",
-     21: "end"}, (0, 2, 3))
-print("===== BACKWARD (workgroup 4096)")
+print("===== BACKWARD (workgroup 4096): cycles since the first wave's start; one column per wave")
 t = trace.cpu().view(8, 128, 2).numpy()
-names = {1: "start", 2: "dma issued", 3: "stage0_ready", 10: "step top barrier passed", 11: "S,dP done", 12: "elementwise done",
-         13: "pair done", 14: "diag store done", 15: "barrier1 passed", 16: "dQ gemm done", 17: "dQ stored",
-         18: "stage dma issued", 19: "dq setup done", 20: "loop done", 21: "end", 22: "dump barrier passed", 23: "dV parked", 24: "final tiles parked"}
+names = {1: "start", 2: "prologue dma issued", 10: "TOP barrier passed", 11: "S,dP done", 12: "elementwise done",
+         13: "pair done", 14: "-", 15: "barrier1 passed", 16: "dQ gemm done", 17: "dQ stored",
+         18: "stage dma+copy-out issued", 19: "dq setup done", 20: "loop done", 21: "end", 22: "dump barrier passed", 23: "dV parked", 24: "final tiles parked"}
 t0 = min(int(t[w, 0, 1]) for w in range(8) if t[w, 0, 0])
-for w in (0, 3, 5, 7):
-    print(f"--- wave {w}")
-    prev = t0
+# waves skip marks 11/12 when they have no pair: align rows by (tag, occurrence)
+rows = []
+occ = [dict() for _ in range(8)]
+table = {}
+for w in range(8):
     for i in range(128):
         tag, ts = int(t[w, i, 0]), int(t[w, i, 1])
         if tag == 0:
             break
-        print(f"  {str(names.get(tag, tag)):>18s}  t={ts - t0:8d}  (+{ts - prev})")
-        prev = ts
+        k = occ[w].get(tag, 0)
+        occ[w][tag] = k + 1
+        table.setdefault((tag, k), {})[w] = ts - t0
+order = sorted(table.items(), key=lambda kv: min(kv[1].values()))
+print(f"{'mark':>28s} " + " ".join(f"{'w' + str(w):>7s}" for w in range(8)))
+for (tag, k), d in order:
+    print(f"{names.get(tag, str(tag)):>25s}#{k} " + " ".join(f"{d[w]:7d}" if w in d else "      ." for w in range(8)))
