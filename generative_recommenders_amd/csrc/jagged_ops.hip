@@ -38,7 +38,7 @@ HSTU_DEV int64_t side_offset(const void* offsets, int b, int max_len, int is64) 
   return offsets ? load_index(offsets, b, is64) : (int64_t)b * max_len;
 }
 
-// grid = (ceil(max_seq_len / kRowsPerBlock), B)
+// grid = (B, ceil(max_seq_len / kRowsPerBlock))
 // SPLIT == false: out[b] = [right[:np] ; left ; right[np:]]   (concat)
 // SPLIT == true : the inverse scatter
 template <int V, bool SPLIT>
@@ -46,13 +46,13 @@ __global__ __launch_bounds__(kCopyThreads) void concat_split_kernel(char* left, 
                                                                     const void* off_l, const void* off_r,
                                                                     int max_len_l, int max_len_r, int row_bytes,
                                                                     int n_prefix, int is64) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.x;   // users on grid.x (2^31 - 1 blocks); grid.y is limited to 65535
   const int64_t ol = side_offset(off_l, b, max_len_l, is64);
   const int64_t orr = side_offset(off_r, b, max_len_r, is64);
   const int ll = (int)(side_offset(off_l, b + 1, max_len_l, is64) - ol);
   const int lr = (int)(side_offset(off_r, b + 1, max_len_r, is64) - orr);
   const int total = ll + lr;
-  const int r_begin = blockIdx.x * kRowsPerBlock;
+  const int r_begin = blockIdx.y * kRowsPerBlock;
   if (r_begin >= total) return;
   const int np = min(n_prefix, lr);
   // threads split as (rows in flight) x (lanes per row)
@@ -77,10 +77,10 @@ __global__ __launch_bounds__(kCopyThreads) void concat_split_kernel(char* left, 
 template <int V, bool TO_DENSE>
 __global__ __launch_bounds__(kCopyThreads) void padded_dense_kernel(char* values, char* dense, const void* offsets,
                                                                     int max_len, int row_bytes, int is64) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.x;   // users on grid.x (2^31 - 1 blocks); grid.y is limited to 65535
   const int64_t off = load_index(offsets, b, is64);
   const int len = min((int)(load_index(offsets, b + 1, is64) - off), max_len);
-  const int r_begin = blockIdx.x * kRowsPerBlock;
+  const int r_begin = blockIdx.y * kRowsPerBlock;
   const int limit = TO_DENSE ? max_len : len;
   if (r_begin >= limit) return;
   const int units = max(row_bytes / V, 1);
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(kCopyThreads) void padded_dense_kernel(char* values
 template <int V>
 __global__ __launch_bounds__(kCopyThreads) void write_tail_kernel(const char* dense, char* values, const void* offsets,
                                                                   int tail, int row_bytes, int is64) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.x;   // users on grid.x (2^31 - 1 blocks); grid.y is limited to 65535
   const int64_t end = load_index(offsets, b + 1, is64);
-  const int r_begin = blockIdx.x * kRowsPerBlock;
+  const int r_begin = blockIdx.y * kRowsPerBlock;
   if (r_begin >= tail) return;
   const int units = max(row_bytes / V, 1);
   int tpr = 1;
@@ -148,10 +148,10 @@ __global__ __launch_bounds__(1024) void complete_cumsum_kernel(const I* in, I* o
 // (B, max_len) <- 1-D jagged, padded with the user's last value (0 when empty)
 template <typename E>
 __global__ void expand_1d_kernel(const E* values, const void* offsets, E* dense, int max_len, int is64) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.x;   // users on grid.x (2^31 - 1 blocks); grid.y is limited to 65535
   const int64_t off = load_index(offsets, b, is64);
   const int len = (int)(load_index(offsets, b + 1, is64) - off);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y * blockDim.x + threadIdx.x;
   if (i >= max_len) return;
   E x = (E)0;
   if (len > 0) x = values[off + min(i, len - 1)];
@@ -180,7 +180,7 @@ static int launch_concat_split(char* left, char* right, char* comb, const void* 
                                int max_len_l, int max_len_r, int max_seq_len, int batch, int row_bytes, int n_prefix,
                                int is64, hipStream_t st) {
   if (batch == 0 || row_bytes == 0 || max_seq_len == 0) return HSTU_OK;
-  dim3 grid((max_seq_len + kRowsPerBlock - 1) / kRowsPerBlock, batch);
+  dim3 grid(batch, (max_seq_len + kRowsPerBlock - 1) / kRowsPerBlock);
   const int v = pick_vec(row_bytes, left, right, comb);
 #define LAUNCH(V)                                                                                              \
   hipLaunchKernelGGL((concat_split_kernel<V, SPLIT>), grid, dim3(kCopyThreads), 0, st, left, right, comb, off_l, \
@@ -200,7 +200,7 @@ template <bool TO_DENSE>
 static int launch_padded(char* values, char* dense, const void* offsets, int batch, int max_len, int row_bytes,
                          int is64, hipStream_t st) {
   if (batch == 0 || row_bytes == 0 || max_len == 0) return HSTU_OK;
-  dim3 grid((max_len + kRowsPerBlock - 1) / kRowsPerBlock, batch);
+  dim3 grid(batch, (max_len + kRowsPerBlock - 1) / kRowsPerBlock);
   const int v = pick_vec(row_bytes, values, dense, nullptr);
 #define LAUNCH(V)                                                                                                 \
   hipLaunchKernelGGL((padded_dense_kernel<V, TO_DENSE>), grid, dim3(kCopyThreads), 0, st, values, dense, offsets, \
@@ -275,7 +275,7 @@ int hstu_jagged_write_tail(const void* dense, void* values, const void* offsets,
   const int row_bytes = dim * elem_bytes;
   const int is64 = index_dtype == HSTU_INDEX_I64;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((tail + kRowsPerBlock - 1) / kRowsPerBlock, batch);
+  dim3 grid(batch, (tail + kRowsPerBlock - 1) / kRowsPerBlock);
 #define LAUNCH(V) hipLaunchKernelGGL((write_tail_kernel<V>), grid, dim3(kCopyThreads), 0, st, (const char*)dense, (char*)values, offsets, tail, row_bytes, is64)
   switch (pick_vec(row_bytes, dense, values, nullptr)) {
     case 16: LAUNCH(16); break;
@@ -292,7 +292,7 @@ int hstu_expand_1d_jagged_to_dense(const void* values, const void* offsets, void
                                    int32_t elem_bytes, int index_dtype, void* stream) {
   if (batch == 0 || max_len == 0) return HSTU_OK;
   if (elem_bytes != 4 && elem_bytes != 8) return set_error(HSTU_EINVAL, "expand_1d_jagged_to_dense: elem_bytes must be 4 or 8");
-  dim3 grid((max_len + 63) / 64, batch);
+  dim3 grid(batch, (max_len + 63) / 64);
   const int is64 = index_dtype == HSTU_INDEX_I64;
   if (elem_bytes == 8)
     hipLaunchKernelGGL(expand_1d_kernel<int64_t>, grid, dim3(64), 0, (hipStream_t)stream, (const int64_t*)values, offsets,

@@ -106,7 +106,7 @@ class STULayer(STU):
         self.kv_caching_offsets: Optional[torch.Tensor] = None
         self.max_kv_caching_len: int = 0
         # persistent [cache ; delta] buffers of the in-place append path (see construct_full_kv)
-        self._kv_full: Optional[Tuple[torch.Tensor, torch.Tensor, int, torch.Tensor]] = None
+        self._kv_full: Optional[Tuple[torch.Tensor, torch.Tensor, tuple, torch.Tensor]] = None
 
     def update_kv_cache(self, max_seq_len: int, seq_offsets: torch.Tensor, k: Optional[torch.Tensor],
                         v: Optional[torch.Tensor], max_kv_caching_len: int,
@@ -136,8 +136,12 @@ class STULayer(STU):
         B = self.kv_caching_offsets.shape[0] - 1
         delta_size = L // B
         in_place = not torch.is_grad_enabled() and not (delta_k.requires_grad or delta_v.requires_grad)
-        if in_place and self._kv_full is not None and self._kv_full[2] == delta_size \
-                and self._kv_full[0].dtype == delta_k.dtype:
+        # the buffers are reused only for the very cache tensors they were built from: k_cache / v_cache /
+        # kv_caching_offsets are public attributes (a caller may assign them directly, as with the reference), so the
+        # key holds their storage pointers, the device and the dtype next to the microbatch size
+        key = (delta_size, delta_k.dtype, delta_k.device, self.k_cache.data_ptr(), self.v_cache.data_ptr(),
+               self.kv_caching_offsets.data_ptr(), self.max_kv_caching_len)
+        if in_place and self._kv_full is not None and self._kv_full[2] == key:
             k_full, v_full, _, full_offsets = self._kv_full
             _launch.jagged_write_tail_(k_full, delta_k, full_offsets, delta_size)
             _launch.jagged_write_tail_(v_full, delta_v, full_offsets, delta_size)
@@ -151,7 +155,7 @@ class STULayer(STU):
         full_offsets = self.kv_caching_offsets + delta_size * torch.arange(
             B + 1, device=delta_k.device, dtype=self.kv_caching_offsets.dtype)
         if in_place:
-            self._kv_full = (full[0], full[1], delta_size, full_offsets)
+            self._kv_full = (full[0], full[1], key, full_offsets)
         return full[0], full[1], self.max_kv_caching_len + delta_size, full_offsets
 
     # ---- forward (stu.py:291-352) ----

@@ -5,11 +5,41 @@ it allocated for the outputs."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
 
 from generative_recommenders_amd import _lib as L
+
+
+# Outputs are torch.empty and the kernels write what the jagged metadata describes -- nothing else.  Rows the metadata
+# does NOT describe stay uninitialised (the reference's padded-dense PyTorch path would truncate / zero them): attention
+# output rows past seq_offsets[-1], delta-attention rows of a user shorter than delta_q, concat / split rows of a user
+# whose left + right length exceeds max_seq_len.  All three are caller errors; HSTU_DEBUG_CHECKS=1 turns them into
+# exceptions (one host sync per call, debugging only).
+DEBUG_CHECKS = os.environ.get("HSTU_DEBUG_CHECKS", "0") not in ("", "0")
+
+
+def _check_attention_metadata(q, seq_offsets, max_seq_len, delta_q) -> None:
+    lengths = (seq_offsets[1:] - seq_offsets[:-1])
+    if bool((lengths < 0).any()):
+        raise RuntimeError("seq_offsets must be non-decreasing")
+    if delta_q > 0:
+        if bool((lengths < delta_q).any()):
+            raise RuntimeError(f"delta attention: a user has fewer than delta_q = {delta_q} rows (its output rows would stay uninitialised)")
+    elif int(seq_offsets[-1]) != q.shape[0]:
+        raise RuntimeError(f"seq_offsets[-1] = {int(seq_offsets[-1])} but q has {q.shape[0]} rows (the rows beyond would stay uninitialised)")
+    if bool((lengths > max_seq_len).any()):
+        raise RuntimeError(f"a user is longer than max_seq_len = {max_seq_len}")
+
+
+def _check_pair_lengths(ol, orr, max_len_left, max_len_right, max_seq_len, batch) -> None:
+    def lens(o, m):
+        return (o[1:] - o[:-1]) if o is not None else torch.full((batch,), int(m), dtype=torch.int64, device=(ol if ol is not None else orr).device)
+    tot = lens(ol, max_len_left).to(torch.int64) + lens(orr, max_len_right).to(torch.int64)
+    if bool((tot > max_seq_len).any()):
+        raise RuntimeError(f"concat / split: a user's left + right length exceeds max_seq_len = {max_seq_len} (rows beyond it are not written)")
 
 
 def _vp(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -74,6 +104,8 @@ def attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_a
     out = torch.empty((q.shape[0], q.shape[1], v.shape[2]), dtype=q.dtype, device=q.device)
     if q.shape[0] == 0:
         return out
+    if DEBUG_CHECKS:
+        _check_attention_metadata(q, seq_offsets, max_seq_len, delta_q)
     p = L.HstuAttnParams()
     _fill_attn_params(p, q, k, v, out, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len,
                       contextual_seq_len, min_full_attn_seq_len, delta_q)
@@ -148,6 +180,8 @@ def concat_2d_jagged(values_left, values_right, offsets_left, offsets_right, max
         batch, idt, ol, orr = vl.shape[0] // max_len_left, 0, None, None
     else:
         ol, orr, idt, batch = _pair_offsets(offsets_left, offsets_right)
+        if DEBUG_CHECKS:
+            _check_pair_lengths(ol, orr, max_len_left, max_len_right, max_seq_len, batch)
     with torch.cuda.device(vl.device):
         L.check(L.lib().hstu_concat_2d_jagged(vl.data_ptr(), vr.data_ptr(), out.data_ptr(), _vp(ol), _vp(orr),
                                               int(max_len_left or 0), int(max_len_right or 0), int(max_seq_len),
@@ -166,6 +200,8 @@ def split_2d_jagged(values, total_left, total_right, offsets_left, offsets_right
     if vals.shape[0] == 0:
         return left, right
     ol, orr, idt, batch = _pair_offsets(offsets_left, offsets_right)
+    if DEBUG_CHECKS:
+        _check_pair_lengths(ol, orr, max_len_left, max_len_right, max_seq_len, batch)
     with torch.cuda.device(vals.device):
         L.check(L.lib().hstu_split_2d_jagged(vals.data_ptr(), left.data_ptr(), right.data_ptr(), _vp(ol), _vp(orr),
                                              int(max_len_left or 0), int(max_len_right or 0), int(max_seq_len),

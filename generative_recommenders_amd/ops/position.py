@@ -4,6 +4,7 @@ over jagged rows.  One HIP kernel forward (indices + gather + add), table gradie
 (csrc/position_ops.hip); semantics of ops/pytorch/pt_position.py:40-134."""
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -13,6 +14,22 @@ from generative_recommenders_amd.common import HammerKernel
 from generative_recommenders_amd.ops._launch import _idx
 
 _FN = {"sqrt": 0, "log": 1}
+
+# Largest time bucket.  The reference has two answers: its GPU path clamps to the last ROW of the timestamp table
+# (ops/triton/triton_position.py:275,295: num_time_buckets = ts_emb.shape[0] - 1), its PyTorch path to
+# ts_embeddings.size(1) - 1, the embedding DIM minus one (ops/pytorch/pt_position.py:101) -- with the shipped shapes
+# (D = 512, 2048 buckets) the latter folds every bucket above 511 (time deltas beyond ~181 days) into one.  Checkpoints
+# are trained on the GPU path, so "table" is the default; "pytorch_path" reproduces the PyTorch branch bit for bit
+# (golden vectors: tests/golden/position.npz are minted from it).
+TIME_BUCKET_CLAMP = os.environ.get("HSTU_TIME_BUCKET_CLAMP", "table")
+
+
+def _max_time_bucket(ts_w: torch.Tensor) -> int:
+    if TIME_BUCKET_CLAMP == "table":
+        return ts_w.shape[0] - 1
+    if TIME_BUCKET_CLAMP == "pytorch_path":
+        return min(ts_w.shape[1] - 1, ts_w.shape[0] - 1)
+    raise RuntimeError(f"TIME_BUCKET_CLAMP must be 'table' or 'pytorch_path', got {TIME_BUCKET_CLAMP!r}")
 
 
 def _table_grad(g: torch.Tensor, idx: torch.Tensor, table_rows: int) -> torch.Tensor:
@@ -43,9 +60,7 @@ class _AddTsPosFunction(torch.autograd.Function):
         out = torch.empty_like(x)
         pos_idx = torch.empty(rows, dtype=torch.int32, device=x.device)
         ts_idx = torch.empty(rows, dtype=torch.int32, device=x.device)
-        # NB the reference clamps the time bucket to ts_embeddings.size(1) - 1 (pt_position.py:101); additionally never
-        # past the last table row
-        max_bucket = min(tw.shape[1] - 1, tw.shape[0] - 1)
+        max_bucket = _max_time_bucket(tw)
         if rows:
             with torch.cuda.device(x.device):
                 L.check(L.lib().hstu_add_ts_pos_emb_fwd(

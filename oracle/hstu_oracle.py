@@ -586,8 +586,8 @@ def position_indices(length, num_target, max_contextual_seq_len, max_pos_ind, in
 def time_bucket_indices(ts_user, max_bucket, time_bucket_fn):
     """bucket of (query time - timestamp) per row of one user (pt_position.py:100-122): fp32 arithmetic exactly as
     torch does it -- int64 difference -> fp32, clamp(min=1e-6), / 60, sqrt | log, truncate, clamp to
-    [0, max_bucket].  NB the reference takes max_bucket = ts_embeddings.size(1) - 1 (the embedding DIM minus one,
-    `:101`), not the number of table rows; restated as is."""
+    [0, max_bucket].  The caller chooses max_bucket: the reference's PyTorch path takes ts_embeddings.size(1) - 1 (the
+    embedding DIM minus one, `:101`), its GPU path the last table row (triton_position.py:275,295)."""
     if len(ts_user) == 0:
         return np.zeros(0, dtype=np.int64)
     d = (ts_user[-1] - ts_user).astype(np.float32)
@@ -598,9 +598,12 @@ def time_bucket_indices(ts_user, max_bucket, time_bucket_fn):
 
 
 def add_timestamp_positional_embeddings_fwd(alpha, x, seq_offsets, timestamps, pos_w, ts_w, max_contextual_seq_len,
-                                            num_targets, interleave_targets, time_bucket_fn):
+                                            num_targets, interleave_targets, time_bucket_fn, bucket_clamp="table"):
     """out[row] = alpha * x[row] + pos_w[pos_idx] + ts_w[ts_idx]  (ops/position.py:55, pt_position.py:123-134).
-    Returns (out, pos_idx, ts_idx) with the per-row table indices."""
+    Returns (out, pos_idx, ts_idx) with the per-row table indices.  bucket_clamp: "table" = the GPU path's clamp to the
+    last table row (triton_position.py:275,295), "pytorch_path" = min(D - 1, last row) (pt_position.py:101; an index
+    past the table would raise there)."""
+    max_bucket = ts_w.shape[0] - 1 if bucket_clamp == "table" else min(ts_w.shape[1] - 1, ts_w.shape[0] - 1)
     B = len(seq_offsets) - 1
     pos_idx = np.zeros(x.shape[0], dtype=np.int64)
     ts_idx = np.zeros(x.shape[0], dtype=np.int64)
@@ -608,7 +611,7 @@ def add_timestamp_positional_embeddings_fwd(alpha, x, seq_offsets, timestamps, p
         o, e = int(seq_offsets[b]), int(seq_offsets[b + 1])
         nt = None if num_targets is None else int(num_targets[b])
         pos_idx[o:e] = position_indices(e - o, nt, max_contextual_seq_len, pos_w.shape[0], interleave_targets)
-        ts_idx[o:e] = time_bucket_indices(np.asarray(timestamps[o:e], dtype=np.int64), ts_w.shape[1] - 1, time_bucket_fn)
+        ts_idx[o:e] = time_bucket_indices(np.asarray(timestamps[o:e], dtype=np.int64), max_bucket, time_bucket_fn)
     out = x * alpha + (ts_w[ts_idx] + pos_w[pos_idx])
     return out, pos_idx, ts_idx
 

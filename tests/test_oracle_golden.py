@@ -194,7 +194,7 @@ def test_oracle_matches_reference_position_encoder(idx):
     nt = c.get("num_targets")
     out, pos_idx, ts_idx = O.add_timestamp_positional_embeddings_fwd(
         float(c["alpha"]), c["x"].astype(np.float64), c["offsets"], c["ts"], c["pos_w"].astype(np.float64),
-        c["ts_w"].astype(np.float64), int(c["ctx"]), nt, bool(c["interleave"]), str(c["fn"]))
+        c["ts_w"].astype(np.float64), int(c["ctx"]), nt, bool(c["interleave"]), str(c["fn"]), bucket_clamp="pytorch_path")
     np.testing.assert_allclose(out, c["out"], rtol=1e-6, atol=1e-6)
     dx, dpos, dts = O.add_timestamp_positional_embeddings_bwd(float(c["alpha"]), c["g"].astype(np.float64), pos_idx,
                                                                ts_idx, c["pos_w"].shape[0], c["ts_w"].shape[0])

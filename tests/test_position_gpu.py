@@ -21,7 +21,10 @@ def _op():
 
 
 @pytest.mark.parametrize("idx", range(3))
-def test_golden_position_encoder_fwd_bwd(idx):
+def test_golden_position_encoder_fwd_bwd(idx, monkeypatch):
+    # the golden vectors come from the reference's PyTorch branch, whose time-bucket clamp is the embedding dim - 1
+    # (pt_position.py:101); the op's default is the GPU branch's (last table row): case 0 (49 rows, D = 32) tells them apart
+    monkeypatch.setattr(_op(), "TIME_BUCKET_CLAMP", "pytorch_path")
     c = load_cases("position.npz")[idx]
     x = torch.from_numpy(c["x"]).to(DEV).requires_grad_()
     pos_w = torch.from_numpy(c["pos_w"]).to(DEV).requires_grad_()
@@ -39,11 +42,17 @@ def test_golden_position_encoder_fwd_bwd(idx):
     np.testing.assert_allclose(ts_w.grad.cpu().numpy(), c["dts_w"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("dtype,D,fn,targets,ctx", [(torch.bfloat16, 512, "sqrt", True, 0), (torch.float32, 64, "log", True, 4),
-                                                    (torch.float16, 128, "sqrt", False, 0), (torch.bfloat16, 1024, "log", True, 2)])
-def test_position_encoder_vs_oracle(dtype, D, fn, targets, ctx):
+@pytest.mark.parametrize("dtype,D,fn,targets,ctx,n_ts,clamp", [
+    (torch.bfloat16, 512, "sqrt", True, 0, 200, "table"),        # clamp at the last table row (199 < sqrt buckets up to 288)
+    (torch.float32, 64, "log", True, 4, 600, "table"),
+    (torch.float16, 128, "sqrt", False, 0, 600, "table"),        # more buckets than the embedding dim: the GPU branch's clamp (599)
+    (torch.float16, 128, "sqrt", False, 0, 600, "pytorch_path"),  # ... and the PyTorch branch's (127)
+    (torch.bfloat16, 1024, "log", True, 2, 600, "table")])
+def test_position_encoder_vs_oracle(dtype, D, fn, targets, ctx, n_ts, clamp, monkeypatch):
     """ragged lengths incl. empty and 1-row users, int32 offsets, segments far longer than one 256-row chunk of the
-    gradient kernel (many rows share a time bucket), tables smaller than the sequence (index clamps)."""
+    gradient kernel (many rows share a time bucket), tables smaller than the sequence (index clamps), both time-bucket
+    clamps of the reference (triton_position.py:275,295 vs pt_position.py:101)."""
+    monkeypatch.setattr(_op(), "TIME_BUCKET_CLAMP", clamp)
     rng = np.random.default_rng(D + ctx)
     B, N = 37, 300
     lengths = rng.integers(ctx + 2, N + 1, size=B)
@@ -54,7 +63,7 @@ def test_position_encoder_vs_oracle(dtype, D, fn, targets, ctx):
     off[1:] = np.cumsum(lengths)
     Lt = int(off[-1])
     ts = np.concatenate([np.sort(rng.integers(0, 5 * 10**6, size=int(l))) for l in lengths]).astype(np.int64)
-    n_pos, n_ts = 128, 600
+    n_pos = 128
     x = torch.from_numpy(rng.standard_normal((Lt, D))).to(dtype)
     pos_w = torch.from_numpy(rng.standard_normal((n_pos, D)) * 0.1).float()
     ts_w = torch.from_numpy(rng.standard_normal((n_ts, D)) * 0.1).float()
@@ -69,9 +78,14 @@ def test_position_encoder_vs_oracle(dtype, D, fn, targets, ctx):
     k_pos, k_ts = (t.cpu().numpy() for t in out.grad_fn.saved_tensors)   # the kernel's table indices
     out.backward(g.to(DEV))
     ref, pos_idx, ts_idx = O.add_timestamp_positional_embeddings_fwd(
-        alpha, x.double().numpy(), off, ts, pos_w.double().numpy(), ts_w.double().numpy(), ctx, nt, False, fn)
+        alpha, x.double().numpy(), off, ts, pos_w.double().numpy(), ts_w.double().numpy(), ctx, nt, False, fn, bucket_clamp=clamp)
     # exact equality with the oracle's integer / fp32-bucket arithmetic
-    assert np.array_equal(k_pos, pos_idx) and np.array_equal(k_ts, np.minimum(ts_idx, n_ts - 1))
+    assert np.array_equal(k_pos, pos_idx) and np.array_equal(k_ts, ts_idx)
+    raw = max(int(O.time_bucket_indices(ts[off[b]:off[b + 1]], 10**9, fn).max()) for b in range(B) if lengths[b] > 0)
+    limit = n_ts - 1 if clamp == "table" else min(D - 1, n_ts - 1)
+    assert ts_idx.max() == min(raw, limit)
+    if fn == "sqrt":
+        assert raw > 199 and (raw > limit) == (n_ts == 200 or clamp == "pytorch_path")   # the clamp is exercised where intended
     rdx, rpos, rts = O.add_timestamp_positional_embeddings_bwd(alpha, g.double().numpy(), pos_idx, ts_idx, n_pos, n_ts)
     tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1e-2)
     np.testing.assert_allclose(out.detach().float().cpu().numpy(), ref, **tol)
