@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime ou
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSTU_HIP_LIBRARY overrides the in-tree build (A/B measurements of kernel variants, packaged installs)
 LIB_PATH = os.environ.get("HSTU_HIP_LIBRARY") or os.path.join(_HERE, "libhstu_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
 HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
@@ -69,6 +69,8 @@ SIGNATURES = {
     "hstu_attn_fwd": (_int, [C.POINTER(HstuAttnParams), _vp]),
     "hstu_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(HstuAttnBwdParams)]),
     "hstu_attn_bwd": (_int, [C.POINTER(HstuAttnBwdParams), _vp]),
+    "hstu_attn_fwd_kernel_name": (_int, [C.POINTER(HstuAttnParams), C.c_char_p, C.c_size_t]),
+    "hstu_attn_bwd_kernel_name": (_int, [C.POINTER(HstuAttnBwdParams), C.c_char_p, C.c_size_t]),
     "hstu_complete_cumsum": (_int, [_vp, _vp, _i64, _int, _vp]),
     "hstu_concat_2d_jagged": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _int, _vp]),
     "hstu_split_2d_jagged": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _int, _vp]),

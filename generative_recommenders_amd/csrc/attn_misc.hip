@@ -1,4 +1,5 @@
 // dtype-independent helpers of the attention ABI.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "capi_internal.h"
@@ -30,6 +31,19 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;
   if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
   return (p.max_seq_len + 31) / 32 <= 7;
+}
+
+// Name of the instantiation attn_launch.cuh / attn_fold.cuh dispatch (the same decisions, restated once here; the
+// launch tests compare it with the kernel names rocprofv3 reports).
+int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char* buf, size_t len) {
+  if (!buf || len == 0) return HSTU_EINVAL;
+  const char* dt = p.dtype == HSTU_DTYPE_BF16 ? "bf16" : (p.dtype == HSTU_DTYPE_F16 ? "f16" : "f32");
+  const int a = pad_head_dim(p.dqk), v = pad_head_dim(p.dv);
+  if (a == 0 || v == 0) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "head dims (%d, %d) not instantiated", p.dqk, p.dv); }
+  if (p.pos_w && a != v) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "relative-bias attention is instantiated for dqk == dv"); }
+  if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
+  else snprintf(buf, len, "hstu_attn_%s_kernel<%s,%d,%d%s>", bwd ? "bwd" : "fwd", dt, a, v, p.pos_w ? ",bias" : "");
+  return HSTU_OK;
 }
 
 // Time buckets are few and lopsided (most pairs of a user fall in the top three or four): the lanes of a wave mostly

@@ -44,7 +44,6 @@ static int validate_attn(const HstuAttnParams& p, const char* who) {
     return set_error(HSTU_EINVAL, "%s: negative mask parameter", who);
   if (p.delta_q < 0) return set_error(HSTU_EINVAL, "%s: negative delta_q", who);
   if (p.pos_w) {
-    if (p.delta_q != 0) return set_error(HSTU_EUNSUPPORTED, "%s: relative bias with delta_q is not supported", who);
     if ((p.ts_w == nullptr) != (p.timestamps == nullptr)) return set_error(HSTU_EINVAL, "%s: ts_w and timestamps must be given together", who);
     if (p.ts_w && (p.num_buckets <= 0 || !(p.bucket_div > 0.f) || p.ts_row_stride < p.max_seq_len))
       return set_error(HSTU_EINVAL, "%s: bad bucket parameters / timestamp stride", who);
@@ -74,6 +73,16 @@ int hstu_attn_fwd(const HstuAttnParams* p, void* stream) {
     case HSTU_DTYPE_F16: return launch_attn_fwd_f16(*p, st);
     default: return launch_attn_fwd_f32(*p, st);
   }
+}
+
+int hstu_attn_fwd_kernel_name(const HstuAttnParams* p, char* buf, size_t len) {
+  if (!p) return set_error(HSTU_EINVAL, "hstu_attn_fwd_kernel_name: NULL params");
+  return attn_kernel_name(*p, nullptr, buf, len);
+}
+
+int hstu_attn_bwd_kernel_name(const HstuAttnBwdParams* p, char* buf, size_t len) {
+  if (!p) return set_error(HSTU_EINVAL, "hstu_attn_bwd_kernel_name: NULL params");
+  return attn_kernel_name(p->fwd, p, buf, len);
 }
 
 size_t hstu_attn_bwd_workspace_bytes(const HstuAttnBwdParams* p) {

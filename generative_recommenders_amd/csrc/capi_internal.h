@@ -29,6 +29,8 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& p);
 int launch_bias_grad_reduce(const float* partial, int rows, int width, int npos, float* dpos_w, float* dts_w,
                             hipStream_t st);
 size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& p);
+// profiler names of the instantiations the launchers above pick (attn_misc.hip)
+int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char* buf, size_t len);
 int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int extra_lds);
 // LDS bytes of the research-path bias state of a backward workgroup (histograms with *ts_copies privatised copies of
 // the time-bucket histogram + the staged tables) and the number of copies chosen; 0 without bias

@@ -148,6 +148,36 @@ def attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale,
     return dq, dk, dv
 
 
+def _shape_params(p: L.HstuAttnParams, dtype, heads, dqk, dv, max_seq_len, alpha, max_attn_len, contextual_seq_len,
+                  min_full_attn_seq_len, with_bias) -> None:
+    p.batch, p.heads, p.dqk, p.dv, p.max_seq_len = 1, int(heads), int(dqk), int(dv), int(max_seq_len)
+    p.alpha, p.scale = float(alpha), 1.0 / max_seq_len
+    p.max_attn_len, p.contextual_seq_len, p.min_full_attn_seq_len = int(max_attn_len), int(contextual_seq_len), int(min_full_attn_seq_len)
+    p.dtype = L.torch_dtype_code(dtype)
+    p.pos_w = 1 if with_bias else None          # only NULL / non-NULL is looked at
+
+
+def attn_fwd_kernel_name(dtype, dqk, dv, max_seq_len, heads=1, alpha=1.0, max_attn_len=0, contextual_seq_len=0,
+                         min_full_attn_seq_len=0, with_bias=False) -> str:
+    """the forward instantiation the library dispatches for this shape (hstu_attn_fwd_kernel_name)"""
+    p = L.HstuAttnParams()
+    _shape_params(p, dtype, heads, dqk, dv, max_seq_len, alpha, max_attn_len, contextual_seq_len, min_full_attn_seq_len, with_bias)
+    buf = C.create_string_buffer(128)
+    L.check(L.lib().hstu_attn_fwd_kernel_name(C.byref(p), buf, 128))
+    return buf.value.decode()
+
+
+def attn_bwd_kernel_name(dtype, dqk, dv, max_seq_len, heads=1, alpha=1.0, max_attn_len=0, contextual_seq_len=0,
+                         min_full_attn_seq_len=0, with_bias=False) -> str:
+    """the backward instantiation the library dispatches for this shape (hstu_attn_bwd_kernel_name)"""
+    bp = L.HstuAttnBwdParams()
+    _shape_params(bp.fwd, dtype, heads, dqk, dv, max_seq_len, alpha, max_attn_len, contextual_seq_len, min_full_attn_seq_len,
+                  with_bias)
+    buf = C.create_string_buffer(128)
+    L.check(L.lib().hstu_attn_bwd_kernel_name(C.byref(bp), buf, 128))
+    return buf.value.decode()
+
+
 # ----------------------------------------------------------------------------- jagged
 def complete_cumsum(lengths: torch.Tensor) -> torch.Tensor:
     L.require_gpu_tensor(lengths, "lengths")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 4
+#define HSTU_ABI_VERSION 5
 
 enum {
   HSTU_OK = 0,
@@ -128,6 +128,14 @@ int hstu_attn_fwd(const HstuAttnParams* p, void* stream);
  * one user's keys do not fit one workgroup. */
 size_t hstu_attn_bwd_workspace_bytes(const HstuAttnBwdParams* p);
 int hstu_attn_bwd(const HstuAttnBwdParams* p, void* stream);
+
+/* Which kernel instantiation hstu_attn_fwd / hstu_attn_bwd dispatches for these shapes, dtype and mask / bias
+ * options (pointers are not dereferenced; only pos_w == NULL or not matters), as the name a profiler shows, e.g.
+ * "hstu_attn_bwd_fold_kernel<bf16,128,128>".  Written NUL-terminated into buf (truncated to len); returns HSTU_OK,
+ * or the code hstu_attn_* would refuse the call with.  The reference exposes the same information only through its
+ * dispatcher branches (ops/hstu_attention.py:87-128, flash_common.cpp:496-507). */
+int hstu_attn_fwd_kernel_name(const HstuAttnParams* p, char* buf, size_t len);
+int hstu_attn_bwd_kernel_name(const HstuAttnBwdParams* p, char* buf, size_t len);
 
 /* out[0] = 0, out[i+1] = sum(in[0..i]); n elements in, n+1 out; dtype preserved.
  * Replaces hstu::complete_cumsum (ops/cpp/complete_cumsum.cu:7-47) and

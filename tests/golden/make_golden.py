@@ -197,7 +197,7 @@ def compute_cases():
     W = (0.1 * torch.randn(D, 2 * H * (A + Hd), generator=gen)).requires_grad_()
     beta = (0.1 * torch.randn(2 * H * (A + Hd), generator=gen)).requires_grad_()
     u, q, k, v = hstu_compute_uqvk(x, nw, nb, 1e-6, H, A, Hd, W, beta, kernel=PT)
-    g = [torch.randn_like(t) for t in (u, q, k, v)]
+    g = [torch.randn(t.shape, generator=gen) for t in (u, q, k, v)]
     (u * g[0]).sum().add((q * g[1]).sum()).add((k * g[2]).sum()).add((v * g[3]).sum()).backward()
     out["uvqk"] = dict(x=_np(x), nw=_np(nw), nb=_np(nb), W=_np(W), beta=_np(beta), H=H, A=A, Hd=Hd,
                        u=_np(u), q=_np(q), k=_np(k), v=_np(v), gu=_np(g[0]), gq=_np(g[1]), gk=_np(g[2]),
@@ -217,7 +217,7 @@ def compute_cases():
                                 output_weight=Wo, num_heads=H, linear_dim=Ld, dropout_ratio=0.0,
                                 training=False, concat_ux=cat, group_norm=gn,
                                 recompute_y_in_backward=False, kernel=PT)
-        gy = torch.randn_like(y)
+        gy = torch.randn(y.shape, generator=gen)
         y.backward(gy)
         out[name] = dict(attn=_np(attn), u=_np(u), x=_np(x), nw=_np(nw), nb=_np(nb), Wo=_np(Wo), H=H, Ld=Ld,
                          gn=gn, cat=cat, y=_np(y), gy=_np(gy), dattn=_np(attn.grad), du=_np(u.grad),
@@ -246,7 +246,7 @@ def stu_case():
     offsets = torch.zeros(B + 1, dtype=torch.int64); offsets[1:] = torch.cumsum(lengths, 0)
     x = torch.randn(int(offsets[-1]), D, generator=gen).requires_grad_()
     y = stack(x=x, x_lengths=lengths, x_offsets=offsets, max_seq_len=N, num_targets=nt)
-    gy = torch.randn_like(y)
+    gy = torch.randn(y.shape, generator=gen)
     y.backward(gy)
     d = dict(D=D, H=H, A=A, Hd=Hd, N=N, lengths=_np(lengths), offsets=_np(offsets), num_targets=_np(nt),
              x=_np(x), y=_np(y), gy=_np(gy), dx=_np(x.grad))
@@ -282,7 +282,7 @@ def research_case():
         num_heads=H, attention_dim=A, linear_dim=Ld, q=q, k=k, v=v, cached_q=None, cached_k=None,
         delta_x_offsets=None, x_offsets=offsets, all_timestamps=ts, invalid_attn_mask=mask,
         rel_attn_bias=bias)
-    g = torch.randn_like(out)
+    g = torch.randn(out.shape, generator=gen)
     out.backward(g)
     return dict(n=n, H=H, A=A, Ld=Ld, offsets=_np(offsets), ts=_np(ts), q=_np(q), k=_np(k), v=_np(v),
                 pos_w=_np(bias._pos_w), ts_w=_np(bias._ts_w), out=_np(out), g=_np(g), dq=_np(q.grad),
@@ -315,7 +315,7 @@ def position_cases():
             alpha=alpha, max_seq_len=N, max_contextual_seq_len=ctx, position_embeddings_weight=pos_w,
             timestamp_embeddings_weight=ts_w, seq_offsets=offsets, seq_lengths=lengths, seq_embeddings=x,
             timestamps=ts, num_targets=nt, interleave_targets=interleave, time_bucket_fn=fn, kernel=PT)
-        g = torch.randn_like(out)
+        g = torch.randn(out.shape, generator=gen)
         out.backward(g)
         cases.append(dict(N=N, D=D, ctx=ctx, interleave=int(interleave), fn=np.asarray(fn), alpha=alpha,
                           offsets=_np(offsets), lengths=_np(lengths), num_targets=None if nt is None else _np(nt),
@@ -470,6 +470,105 @@ def sampled_softmax_cases():
     return cases
 
 
+def _bf16_bits(t):
+    """bf16-representable fp32 tensor -> its 16-bit patterns (half the bytes in the fixture)"""
+    return t.detach().to(torch.bfloat16).view(torch.int16).numpy()
+
+
+def metric_shape_cases():
+    """hstu_mha forward + backward at the shapes the throughput is quoted on: M = N 200, 4 heads of 128
+    (the folded backward kernel's shape) and C2 = N 211, 4 heads of 64, with targets.  The inputs are drawn in fp32 and
+    ROUNDED TO BF16 before the reference (fp32 arithmetic) sees them, so one fixture serves three checks: the fp32
+    kernels on the same values, the bf16 kernels against the exact answer for their own inputs, and -- against the
+    bf16-rounded reference outputs -- the kernels' error without the unavoidable output rounding.  Inputs are stored as
+    bf16 bit patterns."""
+    cases = []
+    for ci, (name, lens, N, H, d, targets) in enumerate([("M", [200, 77], 200, 4, 128, None),
+                                                          ("C2", [211, 100], 211, 4, 64, [6, 3])]):
+        gen = torch.Generator().manual_seed(9000 + ci)
+        lengths = torch.tensor(lens)
+        offsets = torch.zeros(len(lens) + 1, dtype=torch.int64); offsets[1:] = torch.cumsum(lengths, 0)
+        Lt = int(offsets[-1])
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        q = r(torch.randn(Lt, H, d, generator=gen)).requires_grad_()
+        k = r(torch.randn(Lt, H, d, generator=gen)).requires_grad_()
+        v = r(0.5 * torch.randn(Lt, H, d, generator=gen)).requires_grad_()
+        dout = r(0.1 * torch.randn(Lt, H, d, generator=gen))
+        nt = None if targets is None else torch.tensor(targets)
+        alpha = 1.0 / (d**0.5)
+        out = hstu_mha(max_seq_len=N, alpha=alpha, q=q, k=k, v=v, seq_offsets=offsets, causal=True, dropout_pr=0.0,
+                       training=False, num_targets=nt, max_attn_len=0, contextual_seq_len=0, min_full_attn_seq_len=0,
+                       kernel=PT)
+        out.backward(dout)
+        cases.append(dict(name=np.asarray(name), N=N, H=H, d=d, alpha=alpha, offsets=_np(offsets),
+                          num_targets=None if nt is None else _np(nt), q_bf16=_bf16_bits(q), k_bf16=_bf16_bits(k),
+                          v_bf16=_bf16_bits(v), dout_bf16=_bf16_bits(dout), out=_np(out), dq=_np(q.grad), dk=_np(k.grad),
+                          dv_=_np(v.grad)))
+    return cases
+
+
+def research_layer_cases():
+    """The research-path layer end to end: two ``SequentialTransductionUnitJagged`` layers inside ``HSTUJagged``
+    (research/modeling/sequential/hstu.py:226-540), forward + backward with every parameter gradient, the cache states
+    (``return_cache_states``), the INCREMENTAL call (``delta_x_offsets`` / ``cache``: one new last row per user) and the
+    ``all_timestamps=None`` call (no relative bias at all, :205-206)."""
+    from generative_recommenders.research.modeling.sequential.hstu import (
+        HSTUJagged,
+        RelativeBucketedTimeAndPositionBasedBias,
+        SequentialTransductionUnitJagged,
+    )
+    cases = []
+    for ci, concat_ua in enumerate([False, True]):
+        gen = torch.Generator().manual_seed(700 + ci)
+        B, n, D, H, A, Ld = 3, 24, 32, 2, 16, 16
+        torch.manual_seed(11 + ci)
+        layers = [SequentialTransductionUnitJagged(
+            embedding_dim=D, linear_hidden_dim=Ld, attention_dim=A, dropout_ratio=0.0, attn_dropout_ratio=0.0, num_heads=H,
+            linear_activation="silu", relative_attention_bias_module=RelativeBucketedTimeAndPositionBasedBias(
+                max_seq_len=n, num_buckets=128,
+                bucketization_fn=lambda x: (torch.log(torch.abs(x).clamp(min=1)) / 0.301).long()),
+            normalization="rel_bias", linear_config="uvqk", concat_ua=concat_ua, epsilon=1e-6) for _ in range(2)]
+        model = HSTUJagged(layers, autocast_dtype=None)
+        with torch.no_grad():
+            for prm in model.parameters():   # larger than the 0.02 init so that every term matters
+                prm.add_(0.05 * torch.randn(prm.shape, generator=gen))
+        lengths = torch.randint(2, n + 1, (B,), generator=gen)
+        lengths[0] = n
+        offsets = torch.zeros(B + 1, dtype=torch.int64); offsets[1:] = torch.cumsum(lengths, 0)
+        Lt = int(offsets[-1])
+        ts = torch.sort(torch.randint(0, 10**8, (B, n), generator=gen), dim=1).values
+        mask = 1.0 - torch.triu(torch.ones(n, n), diagonal=1)
+        x = torch.randn(Lt, D, generator=gen).requires_grad_()
+        y, cache = model.jagged_forward(x=x, x_offsets=offsets, all_timestamps=ts, invalid_attn_mask=mask,
+                                        return_cache_states=True)
+        g = torch.randn(y.shape, generator=gen)
+        y.backward(g)
+        d = dict(concat_ua=int(concat_ua), B=B, n=n, D=D, H=H, A=A, Ld=Ld, offsets=_np(offsets), ts=_np(ts), x=_np(x),
+                 y=_np(y), g=_np(g), dx=_np(x.grad))
+        for name, prm in model.named_parameters():
+            d["p:" + name] = _np(prm)
+            d["g:" + name] = _np(prm.grad)
+        for li, (cv, cq, ck, co) in enumerate(cache):
+            d.update({f"cache{li}:v": _np(cv), f"cache{li}:q": _np(cq), f"cache{li}:k": _np(ck), f"cache{li}:out": _np(co)})
+        # incremental: every user's LAST row is replaced by a new item; the caches of the call above stand for the
+        # state before it (their last rows are overwritten by the call, as the reference's index_copy_ does)
+        with torch.no_grad():
+            rows = offsets[1:] - 1
+            cols = lengths - 1
+            x2 = x.detach().clone()
+            x2[rows] = torch.randn(B, D, generator=gen)
+            cache_in = [tuple(t.detach().clone() for t in c) for c in cache]
+            y2, cache2 = model.jagged_forward(x=x2, x_offsets=offsets, all_timestamps=ts, invalid_attn_mask=mask,
+                                              delta_x_offsets=(rows, cols), cache=cache_in, return_cache_states=True)
+            y_full, _ = model.jagged_forward(x=x2, x_offsets=offsets, all_timestamps=ts, invalid_attn_mask=mask)
+            y_nobias, _ = model.jagged_forward(x=x.detach(), x_offsets=offsets, all_timestamps=None, invalid_attn_mask=mask)
+        d.update(x2=_np(x2), delta_rows=_np(rows), delta_cols=_np(cols), y2=_np(y2), y2_full=_np(y_full), y_nobias=_np(y_nobias))
+        for li, (cv, cq, ck, co) in enumerate(cache2):
+            d.update({f"cache2_{li}:v": _np(cv), f"cache2_{li}:q": _np(cq), f"cache2_{li}:k": _np(ck), f"cache2_{li}:out": _np(co)})
+        cases.append(d)
+    return cases
+
+
 def _save_cases(path, cases):
     flat = {}
     for i, c in enumerate(cases):
@@ -482,22 +581,30 @@ def _save_cases(path, cases):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=HERE, help="directory the .npz files are written to (default: next to this script)")
+    ap.add_argument("--only", default="", help="comma-separated fixture names (without .npz); default: all")
+    args = ap.parse_args()
     torch.set_num_threads(1)
-    _save_cases(os.path.join(HERE, "attention.npz"), attention_cases())
-    _save_cases(os.path.join(HERE, "delta_attention.npz"), delta_cases())
-    jc, l2 = jagged_cases()
-    _save_cases(os.path.join(HERE, "jagged.npz"), jc)
-    _save_cases(os.path.join(HERE, "jagged_l2.npz"), [l2])
-    cc = compute_cases()
-    _save_cases(os.path.join(HERE, "compute.npz"), [dict(name=np.asarray(n), **c) for n, c in cc.items()])
-    _save_cases(os.path.join(HERE, "stu.npz"), [stu_case()])
-    _save_cases(os.path.join(HERE, "research_attention.npz"), [research_case()])
-    _save_cases(os.path.join(HERE, "position.npz"), position_cases())
-    _save_cases(os.path.join(HERE, "postprocess.npz"), postprocess_cases())
-    _save_cases(os.path.join(HERE, "sampled_softmax.npz"), sampled_softmax_cases())
-    for f in sorted(os.listdir(HERE)):
+    OUT = args.out
+    os.makedirs(OUT, exist_ok=True)
+    only = set(filter(None, args.only.split(",")))
+    jobs = [
+        ("attention", attention_cases), ("delta_attention", delta_cases), ("jagged", lambda: jagged_cases()[0]),
+        ("jagged_l2", lambda: [jagged_cases()[1]]),
+        ("compute", lambda: [dict(name=np.asarray(n), **c) for n, c in compute_cases().items()]),
+        ("stu", lambda: [stu_case()]), ("research_attention", lambda: [research_case()]), ("position", position_cases),
+        ("postprocess", postprocess_cases), ("sampled_softmax", sampled_softmax_cases),
+        ("metric_shapes", metric_shape_cases), ("research_layer", research_layer_cases),
+    ]
+    for name, fn in jobs:
+        if only and name not in only:
+            continue
+        _save_cases(os.path.join(OUT, name + ".npz"), fn())
+    for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
-            print(f, os.path.getsize(os.path.join(HERE, f)))
+            print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
 if __name__ == "__main__":

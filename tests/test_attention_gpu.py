@@ -3,14 +3,18 @@
 seeded inputs drawn like the reference's own tests (ops/tests/hstu_attention_test.py:62-120,
 parameter space of SURVEY.md App. E).
 
-Tolerances (stated once, used everywhere):
+Tolerances (stated once, used everywhere; the Frobenius gates are 1.5 x the largest error MEASURED on MI355X over this
+file's cases -- profiles/r02_parity_errors.md):
   fp32 I/O : element-wise |err| <= 1e-3 * |ref| + 1e-6 * max|ref|      (north_star: 1e-3 rel)
-  bf16/fp16: relative Frobenius error <= 4e-3 and element-wise
-             |err| <= 2e-2 * |ref| + 4e-3 * max|ref|.
-             (Rounding the EXACT result to bf16 already costs 2^-9/sqrt(3) = 1.1e-3 relative
-             RMS, and P is rounded to bf16 before the second MFMA exactly as the reference's
-             Triton kernel does, so 1e-3 is not reachable with bf16 outputs by any kernel;
-             the reference's own bf16 test tolerance is rtol=1.6e-2.)
+             and relative Frobenius error <= 2.5e-6                     (measured <= 1.5e-6)
+  bf16     : relative Frobenius error <= 3.8e-3                         (measured 2.34e-3 .. 2.49e-3)
+             and element-wise |err| <= 2e-2 * |ref| + 4e-3 * max|ref|.
+             The measured error is sqrt(2) x 1.66e-3: rounding the EXACT result of normally distributed values to
+             bf16 costs 1.66e-3 relative Frobenius by itself, and P is rounded to bf16 before the second MFMA exactly
+             as the reference's Triton kernel does -- one more rounding of the same size; everything else the
+             kernels do is below 1e-4.  1e-3 is not reachable with bf16 outputs by any kernel; the reference's own
+             bf16 test tolerance is rtol = 1.6e-2.
+  fp16     : relative Frobenius error <= 4.5e-4                         (measured 2.9e-4 = sqrt(2) x 2.08e-4)
   fp16     : additionally one fp16 subnormal quantum (2^-24) of absolute slack per element: with
              the reference test's input distribution (uniform +-0.1, small head dims, /N) the true
              outputs are ~1e-5, i.e. BELOW fp16's smallest normal 6.1e-5, so any fp16 output
@@ -23,7 +27,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_cases
+from conftest import load_cases, record_parity
 from oracle import hstu_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -44,13 +48,16 @@ def check_close(got: torch.Tensor, ref: np.ndarray, dtype, what=""):
     assert np.isfinite(g).all(), f"{what}: non-finite values"
     scale = max(np.abs(ref).max(), 1e-30)
     err = np.abs(g - ref)
+    quantum = 2.0**-24 if dtype == torch.float16 else 0.0
+    record_parity(what, g, ref, str(dtype).replace("torch.", ""),
+                  rel_fro_after_fp16_quantum=float(np.linalg.norm(np.maximum(err - quantum, 0.0)) / max(np.linalg.norm(ref), 1e-30)))
+    resid = np.maximum(err - quantum, 0.0)
+    fro = np.linalg.norm(resid) / max(np.linalg.norm(ref), 1e-30)
+    gate = {torch.float32: 2.5e-6, torch.bfloat16: 3.8e-3, torch.float16: 4.5e-4}[dtype]
+    assert fro <= gate, f"{what}: relative Frobenius error {fro:.3e} (gate {gate})"
     if dtype == torch.float32:
         bad = err > 1e-3 * np.abs(ref) + 1e-6 * scale
     else:
-        quantum = 2.0**-24 if dtype == torch.float16 else 0.0
-        resid = np.maximum(err - quantum, 0.0)
-        fro = np.linalg.norm(resid) / max(np.linalg.norm(ref), 1e-30)
-        assert fro <= 4e-3, f"{what}: relative Frobenius error {fro:.3e}"
         bad = err > 2e-2 * np.abs(ref) + 4e-3 * scale + quantum
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements out of tolerance, max err {err.max():.3e} (scale {scale:.3e})"
 

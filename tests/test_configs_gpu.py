@@ -12,6 +12,8 @@ and through size-independent properties where it does not (C5: N up to 8192).
 """
 import numpy as np
 import pytest
+
+from conftest import record_parity
 import torch
 
 from oracle import hstu_oracle as O
@@ -32,9 +34,10 @@ def _research():
     return R
 
 
-def _rel(got, ref):
+def _rel(got, ref, what=""):
+    dtype_name = str(got.dtype).replace("torch.", "")
     got = got.detach().double().cpu().numpy().reshape(ref.shape)
-    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+    return record_parity(what, got, ref, dtype_name)["rel_fro"]
 
 
 def _offsets(lengths):
@@ -100,13 +103,16 @@ def test_research_configs_rel_bias_attention(name, B, n, H, d, dtype, lengths_ki
     q3, k3, v3 = (t.double().numpy().reshape(Lt, H, d) for t in (q, k, v))
     ref = O.rel_bias_attention_fwd(n, q3, k3, v3, off, ts, pw, tw)
     rq, rk, rv, rpos, rts = O.rel_bias_attention_bwd(n, g.double().numpy().reshape(Lt, H, d), q3, k3, v3, off, ts, pw, tw)
-    tol = 1e-3 if dtype == torch.float32 else 6e-3        # relative Frobenius; bf16 output rounding alone is 1.1e-3
-    assert _rel(out, ref.reshape(Lt, -1)) < tol
-    assert _rel(qd.grad, rq.reshape(Lt, -1)) < tol
-    assert _rel(kd.grad, rk.reshape(Lt, -1)) < tol
-    assert _rel(vd.grad, rv.reshape(Lt, -1)) < tol
-    assert _rel(pos_w.grad, rpos) < (2e-3 if dtype == torch.float32 else 2e-2)
-    assert _rel(ts_w.grad, rts) < (2e-3 if dtype == torch.float32 else 2e-2)
+    # relative Frobenius, 1.5 x measured (profiles/r02_parity_errors.md: 2.6e-7 / 2.36e-3; bf16 = two roundings of 1.66e-3)
+    tol = 1e-6 if dtype == torch.float32 else 3.6e-3
+    assert _rel(out, ref.reshape(Lt, -1), "out") < tol
+    assert _rel(qd.grad, rq.reshape(Lt, -1), "dq") < tol
+    assert _rel(kd.grad, rk.reshape(Lt, -1), "dk") < tol
+    assert _rel(vd.grad, rv.reshape(Lt, -1), "dv") < tol
+    # table gradients are fp32 sums of dS' (taken before any 16-bit rounding) whatever the I/O dtype: measured <= 5.5e-7;
+    # 3e-6 leaves room for the summation order of the LDS float atomics, which is not fixed
+    assert _rel(pos_w.grad, rpos, f"dpos_w[{dtype} attention]") < 3e-6
+    assert _rel(ts_w.grad, rts, f"dts_w[{dtype} attention]") < 3e-6
 
 
 def test_c2_ops_path_attention_bf16():
@@ -127,7 +133,7 @@ def test_c2_ops_path_attention_bf16():
     ref = O.hstu_mha_fwd(N, d**-0.5, f(q), f(k), f(v), off, num_targets=nt)
     rq, rk, rv = O.hstu_mha_bwd(N, d**-0.5, f(g), f(q), f(k), f(v), off, num_targets=nt)
     for got, want, what in ((out, ref, "out"), (qd.grad, rq, "dq"), (kd.grad, rk, "dk"), (vd.grad, rv, "dv")):
-        assert _rel(got, want) < 4e-3, what
+        assert _rel(got, want, what) < 3.6e-3, what
 
 
 # ---------------------------------------------------------------------------------------------- C4
@@ -152,7 +158,7 @@ def test_c4_one_rank_shard_of_the_dp8_batch():
     ref = O.hstu_mha_fwd(N, d**-0.5, f(q), f(k), f(v), off[: nb + 1])
     rq, rk, rv = O.hstu_mha_bwd(N, d**-0.5, f(g), f(q), f(k), f(v), off[: nb + 1])
     for got, want, what in ((out[:Lb], ref, "out"), (q.grad[:Lb], rq, "dq"), (k.grad[:Lb], rk, "dk"), (v.grad[:Lb], rv, "dv")):
-        assert _rel(got, want) < 4e-3, what
+        assert _rel(got, want, what) < 3.6e-3, what
     # the rest of the shard: the same users in a different batch give the same bits
     lo, hi = 700, 900
     s, e = int(off[lo]), int(off[hi])
@@ -182,6 +188,6 @@ def test_c5_delta_q_microbatch_long_history():
     dl = _ops().delta_hstu_mha(N, d**-0.5, dq, k, v, offt, num_targets=nt)
     f = lambda t: t.double().cpu().numpy()
     ref = O.delta_hstu_mha_fwd(N, d**-0.5, f(dq), f(k), f(v), off, num_targets=np.full(B, delta, dtype=np.int64))
-    assert _rel(dl, ref) < 4e-3
+    assert _rel(dl, ref, "delta out") < 3.6e-3
     full = _ops().hstu_mha(N, d**-0.5, q, k, v, offt, num_targets=nt)
     assert torch.equal(dl, full[idx])

@@ -187,6 +187,27 @@ def test_mask_zero_history_and_properties():
     assert m[7, :6].all() and m[7, 7] and not m[7, 6]
 
 
+def _bf16_bits_to_f64(bits):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(bits)).view(torch.bfloat16).double().numpy()
+
+
+@pytest.mark.parametrize("idx", range(2))
+def test_oracle_matches_reference_at_the_metric_shapes(idx):
+    """M (N = 200, 4 heads of 128) and C2 (N = 211, 4 heads of 64, targets): the shapes the throughput is quoted on
+    (tests/golden/make_golden.py::metric_shape_cases).  The oracle runs in fp64, the reference in fp32."""
+    c = load_cases("metric_shapes.npz")[idx]
+    q, k, v, do = (_bf16_bits_to_f64(c[n]) for n in ("q_bf16", "k_bf16", "v_bf16", "dout_bf16"))
+    nt = c.get("num_targets")
+    out = O.hstu_mha_fwd(int(c["N"]), float(c["alpha"]), q, k, v, c["offsets"], nt)
+    dq, dk, dv = O.hstu_mha_bwd(int(c["N"]), float(c["alpha"]), do, q, k, v, c["offsets"], nt)
+    for name, got, want in (("out", out, c["out"]), ("dq", dq, c["dq"]), ("dk", dk, c["dk"]), ("dv", dv, c["dv_"])):
+        rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+        assert rel < 2e-6, f"{name}: relative Frobenius difference {rel:.2e} (fp32 reference vs fp64 oracle)"
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5 * np.abs(want).max())
+
+
 # ------------------------------------------------------------------ §8f rank 1: timestamp / position encoder
 @pytest.mark.parametrize("idx", range(3))
 def test_oracle_matches_reference_position_encoder(idx):
