@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- HSTU attention fwd+bwd throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload M-full|M-jag|M-targets|C2|C3|C4|C5]
 
-A *step* is one pass of the hot path -- hstu attention forward + backward through the
-C ABI (libhstu_hip.so) -- over one batch of synthetic jagged user sequences that is already
-resident in HBM.  Metric shape M: N=200, H=4, dqk=dv=128 (d=512), bf16,
-8192 users per GPU; q, k, v are strided views of one fused (sum L, H, 3*128) buffer drawn
-uniform(-0.01, 0.01) with seed 1001 (as ops/benchmarks/hstu_attention_bench.py:194-233
-builds them); dout = randn.  Users shard across ranks (weak scaling: per-GPU work fixed);
-attention has no parameters, hence no collective in the timed region -- the ranks only
-meet at the barriers that bracket it.  The secondary "layer" section times 3 STU layers
-(D=512) fwd+bwd WITH the RCCL gradient all-reduce inside the step.
+A *step* is one pass of the hot path -- hstu attention forward + backward through the C ABI (libhstu_hip.so) -- over one
+batch of synthetic jagged user sequences that is already resident in HBM.  Default workload = the metric shape M
+(SURVEY.md 8d): N=200, H=4, dqk=dv=128 (d=512), bf16, 8192 users per GPU; q, k, v are strided views of one fused
+(sum L, H, 3*128) buffer drawn uniform(-0.01, 0.01) with seed 1001 (as ops/benchmarks/hstu_attention_bench.py:194-233
+builds them); dout = randn.  The other workloads are the remaining BASELINE.json configurations as synthetic inputs
+(SURVEY 8d "Other configs"): C2 research-path relative-bias attention (N=211, 4x64), C3 Amazon-Books-like long-tail
+lengths (N=61, 4x16), C4 one rank's shard of the DP-8 batch (N=200, 4x64), C5 delta-q microbatches over long
+histories (16x64, N<=8192, forward only, 24 layers back to back).
+
+N > 1: one process per GPU.  Under ``torch.distributed.run`` the ranks come from the environment; called plainly with
+``--gpus N`` the script spawns its N ranks itself (as the reference's main.py:68-78 does).  Users shard across ranks (weak
+scaling: per-GPU work fixed); attention has no parameters, hence no collective in the timed region -- the ranks meet at
+the barriers that bracket it.  The secondary "layer" section times 3 STU layers (D=512) fwd+bwd WITH the RCCL gradient
+all-reduce inside the step, and the "rccl" object reports the communicator size and the bus bandwidth of the 22 MB
+all-reduce that step performs.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with the extra objects
-  roofline     -- dominant kernel (backward): algorithmic bytes / HIP-event kernel time vs 8 TB/s
-  cpu_baseline -- the padded-dense CPU port of the reference's PyTorch path on the host cores
+  roofline      -- dominant kernel (backward): algorithmic bytes / HIP-event kernel time vs 8 TB/s; kernel names come from
+                   the library (hstu_attn_*_kernel_name); ``traffic`` = HBM bytes from committed PMC passes of the SAME
+                   workload / dtype / head dim / users (``traffic_source`` says which), null otherwise
+  cpu_baseline  -- the padded-dense CPU port of the reference's PyTorch path on the host cores (attention and 3 STU layers)
 """
 
 import argparse
 import json
 import os
+import socket
 import statistics
 import sys
 import time
@@ -32,79 +41,158 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ~6.3 TB/s
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4 copy 6.29 TB/s
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
+
+# workload -> (max_seq_len, heads, head_dim, default users per GPU, description)
+WORKLOADS = {
+    "M-full": (200, 4, 128, 8192, "every user has L = 200"),
+    "M-jag": (200, 4, 128, 8192, "L = randint(180, 200) (generate_sparse_seq_len, sparsity 0.95)"),
+    "M-targets": (200, 4, 128, 8192, "M-jag lengths, num_targets = randint(1, 21) (general mask algebra)"),
+    "C2": (211, 4, 64, 8192, "ML-20M shape, research path: relative position + time-bucket bias inside the kernels, L = randint(1, 212)"),
+    "C3": (61, 4, 16, 8192, "Amazon-Books shape, long-tail lengths: randint(0, 30), 5 % of the users at the full 61"),
+    "C4": (200, 4, 64, 1024, "one rank's shard (1024 users) of the DP-8 synthetic ML-3B batch, M-jag lengths"),
+    "C5": (8192, 16, 64, 32, "HSTU-large M-FALCON microbatch: 256 candidates per user against L = randint(7372, 8192) cached rows, forward only, 24 layers back to back"),
+}
 
 
 def make_lengths(workload, B, N, gen, device):
     if workload == "M-full":
         return torch.full((B,), N, dtype=torch.int64, device=device)
+    if workload == "C2":
+        return torch.randint(1, N + 1, (B,), generator=gen, device=device, dtype=torch.int64)
+    if workload == "C3":
+        lengths = torch.randint(0, 30, (B,), generator=gen, device=device, dtype=torch.int64)
+        full = torch.rand(B, generator=gen, device=device) < 0.05
+        return torch.where(full, torch.full_like(lengths, N), lengths)
     lo = int(0.9 * N)  # generate_sparse_seq_len(sparsity=0.95): randint(int(0.9 N), N)
     return torch.randint(lo, N, (B,), generator=gen, device=device, dtype=torch.int64)
 
 
+def _event_ms(pairs):
+    return statistics.mean(a.elapsed_time(b) for a, b in pairs)
+
+
 def attention_section(args, rank, world, device):
+    """the timed region of the headline number: K steps of attention fwd (+ bwd), bracketed by barrier + synchronize"""
     from generative_recommenders_amd import data_parallel as dp
     from generative_recommenders_amd.ops import _launch
 
+    wl = args.workload
     N, H, d = args.max_seq_len, args.heads, args.head_dim
     B = args.users_per_gpu
     gen = torch.Generator(device=device).manual_seed(1001 + rank)
-    lengths = make_lengths(args.workload if args.workload != "M-targets" else "M-jag", B, N, gen, device)
+    lengths = make_lengths(wl if wl not in ("M-targets", "C4", "C5") else "M-jag", B, N, gen, device)
     off = dp.local_offsets(lengths)
     L = int(off[-1].item())
     dtype = torch.bfloat16
-    fused = torch.empty(L, H, 3 * d, device=device, dtype=dtype).uniform_(-0.01, 0.01, generator=gen)
-    q, k, v = torch.split(fused, [d, d, d], dim=-1)
-    if os.environ.get("HSTU_BENCH_LAYOUT") == "separate":   # experiment: contiguous (L, H, d) tensors
-        q, k, v = (t.contiguous() for t in (q, k, v))
-    elif os.environ.get("HSTU_BENCH_LAYOUT") == "headmajor":   # experiment: each head's rows contiguous (H, L, d)
-        q, k, v = (t.permute(1, 0, 2).contiguous().permute(1, 0, 2) for t in (q, k, v))
-    dout = torch.randn(L, H, d, device=device, dtype=dtype, generator=gen)
-    nt = None
-    if args.workload == "M-targets":
-        nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
-    dfused = torch.empty_like(fused)
-    dq, dk, dv = torch.split(dfused, [d, d, d], dim=-1)
+    es = 2
     alpha = d**-0.5
+    fwd_only = wl == "C5"
+    kernels = {}
 
-    def step():
-        out = _launch.attn_fwd(q, k, v, off, nt, N, alpha, 1.0 / N)
-        _launch.attn_bwd(dout, q, k, v, off, nt, N, alpha, 1.0 / N, dq=dq, dk=dk, dv=dv)
-        return out
+    if wl == "C5":
+        delta, layers = 256, 24
+        k = torch.empty(L, H, d, device=device, dtype=dtype).uniform_(-0.01, 0.01, generator=gen)
+        v = torch.empty(L, H, d, device=device, dtype=dtype).uniform_(-0.01, 0.01, generator=gen)
+        dq_ = torch.empty(B * delta, H, d, device=device, dtype=dtype).uniform_(-0.01, 0.01, generator=gen)
+        nt = torch.full((B,), delta, dtype=torch.int64, device=device)
+
+        def fwd():
+            out = None
+            for _ in range(layers):
+                out = _launch.attn_fwd(dq_, k, v, off, nt, N, alpha, 1.0 / N, delta_q=delta)
+            return out
+
+        bwd = None
+        fwd_bytes = layers * (L * H * 2 * d + 2 * B * delta * H * d) * es
+        bwd_bytes = 0
+        flops = layers * 4.0 * H * d * delta * float(L)            # every candidate row sees its user's whole history
+        kernels["fwd"] = _launch.attn_fwd_kernel_name(dtype, d, d, N, heads=H)
+        finite = lambda o: bool(torch.isfinite(o.float()).all())
+    elif wl == "C2":
+        from generative_recommenders_amd.research.modeling.sequential import hstu as R
+
+        torch.manual_seed(5)
+        bias = R.RelativeBucketedTimeAndPositionBasedBias(N, 128).to(device)
+        ts = torch.sort(torch.randint(0, 10**8, (B, N), generator=gen, device=device), dim=1).values
+        q, k, v = (torch.empty(L, H * d, device=device, dtype=dtype).normal_(0, 0.3, generator=gen).requires_grad_() for _ in range(3))
+        g = torch.randn(L, H * d, device=device, dtype=dtype, generator=gen)
+        state = {}
+
+        def fwd():
+            state["out"] = R.hstu_rel_bias_attention(H, d, d, q, k, v, off, ts, N, bias)
+            return state["out"]
+
+        def bwd():
+            return torch.autograd.grad(state["out"], (q, k, v, bias._pos_w, bias._ts_w), g)
+
+        fwd_bytes = L * H * 4 * d * es + B * N * 8
+        bwd_bytes = L * H * 7 * d * es + B * N * 8
+        flops = float(sum(7.0 * H * d * float(x) * float(x) for x in lengths.tolist()))
+        kernels["fwd"] = _launch.attn_fwd_kernel_name(dtype, d, d, N, heads=H, with_bias=True)
+        kernels["bwd"] = _launch.attn_bwd_kernel_name(dtype, d, d, N, heads=H, with_bias=True)
+        finite = lambda o: bool(torch.isfinite(o.float()).all())
+    else:
+        fused = torch.empty(L, H, 3 * d, device=device, dtype=dtype).uniform_(-0.01, 0.01, generator=gen)
+        q, k, v = torch.split(fused, [d, d, d], dim=-1)
+        if os.environ.get("HSTU_BENCH_LAYOUT") == "separate":   # experiment: contiguous (L, H, d) tensors
+            q, k, v = (t.contiguous() for t in (q, k, v))
+        elif os.environ.get("HSTU_BENCH_LAYOUT") == "headmajor":   # experiment: each head's rows contiguous (H, L, d)
+            q, k, v = (t.permute(1, 0, 2).contiguous().permute(1, 0, 2) for t in (q, k, v))
+        dout = torch.randn(L, H, d, device=device, dtype=dtype, generator=gen)
+        nt = None
+        if wl == "M-targets":
+            nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
+        dfused = torch.empty_like(fused)
+        dq, dk, dv = torch.split(dfused, [d, d, d], dim=-1)
+
+        def fwd():
+            return _launch.attn_fwd(q, k, v, off, nt, N, alpha, 1.0 / N)
+
+        def bwd():
+            return _launch.attn_bwd(dout, q, k, v, off, nt, N, alpha, 1.0 / N, dq=dq, dk=dk, dv=dv)
+
+        fwd_bytes = L * H * (2 * d + 2 * d) * es
+        bwd_bytes = L * H * (4 * d + 3 * d) * es
+        # fwd+bwd, causal-halved (hstu_attention_bench.py:35-59): 4 f1 + 3 f2 per user
+        flops = float(sum(7.0 * H * d * float(x) * float(x) for x in lengths.tolist())) if B <= 100000 else 0.0
+        tg = dict(max_attn_len=0)
+        kernels["fwd"] = _launch.attn_fwd_kernel_name(dtype, d, d, N, heads=H, alpha=alpha, **tg)
+        kernels["bwd"] = _launch.attn_bwd_kernel_name(dtype, d, d, N, heads=H, alpha=alpha, **tg)
+        finite = lambda o: bool(torch.isfinite(o.float()).all() and torch.isfinite(dfused.float()).all())
 
     for _ in range(args.warmup):
-        step()
+        fwd()
+        if bwd is not None:
+            bwd()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    out = None
     for i in range(args.steps):
         ev[i][0].record()
-        out = _launch.attn_fwd(q, k, v, off, nt, N, alpha, 1.0 / N)
+        out = fwd()
         ev[i][1].record()
-        _launch.attn_bwd(dout, q, k, v, off, nt, N, alpha, 1.0 / N, dq=dq, dk=dk, dv=dv)
+        if bwd is not None:
+            bwd()
         ev[i][2].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = dp.max_over_ranks(t1 - t0, device)
-    fwd_ms = statistics.mean(e[0].elapsed_time(e[1]) for e in ev)
-    bwd_ms = statistics.mean(e[1].elapsed_time(e[2]) for e in ev)
-    total_L = dp.sum_over_ranks(float(L), device)
-    es = 2
-    fwd_bytes = L * H * (2 * d + 2 * d) * es
-    bwd_bytes = L * H * (4 * d + 3 * d) * es
-    flops_user = lambda Lb: 4 * H * d * Lb * Lb + 3 * H * d * Lb * Lb  # fwd+bwd, causal-halved (bench :35-59)
-    flops = float(sum(flops_user(float(x)) for x in lengths.tolist())) if B <= 100000 else 0.0
-    assert torch.isfinite(out.float()).all() and torch.isfinite(dfused.float()).all()
+    fwd_ms = _event_ms([(e[0], e[1]) for e in ev])
+    bwd_ms = _event_ms([(e[1], e[2]) for e in ev]) if bwd is not None else 0.0
+    assert finite(out), "non-finite values in the benchmark outputs"
     return dict(
-        elapsed=elapsed, users=B, rows=L, total_rows=total_L, fwd_ms=fwd_ms, bwd_ms=bwd_ms,
-        fwd_gbps=fwd_bytes / fwd_ms / 1e6, bwd_gbps=bwd_bytes / bwd_ms / 1e6,
+        elapsed=elapsed, users=B, rows=L, total_rows=dp.sum_over_ranks(float(L), device), fwd_ms=fwd_ms, bwd_ms=bwd_ms,
+        fwd_gbps=fwd_bytes / fwd_ms / 1e6, bwd_gbps=(bwd_bytes / bwd_ms / 1e6) if bwd_ms else 0.0,
         both_gbps=(fwd_bytes + bwd_bytes) / (fwd_ms + bwd_ms) / 1e6, bwd_bytes=bwd_bytes, fwd_bytes=fwd_bytes,
-        tflops=flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
+        tflops=flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12, kernels=kernels, fwd_only=fwd_only,
+        device_ms_per_step=fwd_ms + bwd_ms,
     )
 
 
@@ -123,13 +211,38 @@ def copy_bandwidth(device):
     return 2 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def rccl_section(world, device, nbytes=22 << 20):
+    """communicator size + bus bandwidth of the all-reduce the layer step performs (22 MB of fp32 gradients)"""
+    if world == 1 or not dist.is_initialized():
+        return None
+    t = torch.ones(nbytes // 4, dtype=torch.float32, device=device)
+    for _ in range(3):
+        dist.all_reduce(t)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dist.barrier()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(t)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    from generative_recommenders_amd import data_parallel as dp
+
+    dt = dp.max_over_ranks(dt, device)
+    return dict(backend=dist.get_backend(), ranks=dist.get_world_size(), allreduce_bytes=nbytes, allreduce_ms=dt * 1e3,
+                busbw_GBps=2.0 * (world - 1) / world * nbytes / dt / 1e9)
+
+
 def layer_section(args, rank, world, device):
     """3 x STULayer (D=512, H=4, dqk=dv=128, group norm, target-aware) fwd+bwd + gradient
     all-reduce, bf16 activations (DLRM-v3 HSTU config, dlrm_v3/configs.py:30-41)."""
     from generative_recommenders_amd import data_parallel as dp
     from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig, STUStack
 
-    N, H, d, D = args.max_seq_len, args.heads, args.head_dim, args.heads * args.head_dim
+    N, H, d = 200, 4, 128
+    D = H * d
     B = args.layer_users_per_gpu
     gen = torch.Generator(device=device).manual_seed(2002 + rank)
     lengths = make_lengths("M-jag", B, N, gen, device)
@@ -169,7 +282,41 @@ def layer_section(args, rank, world, device):
     return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,
                 user_seqs_per_s=world * B * args.layer_steps / elapsed, params=nparams,
                 allreduce_bytes=nparams * 4,
-                gemm_mfma_frac_if_all_time_were_gemm=gemm_flops * args.layer_steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS)
+                gemm_mfma_frac_if_all_time_were_gemm=gemm_flops * args.layer_steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,
+                projections=projection_section(L, D, device))
+
+
+def projection_section(rows, D, device):
+    """MFMA utilisation of the six projection GEMMs of one STU layer at the layer section's shape (hipBLASLt through
+    torch, bf16; ops/hstu_compute.py): TFLOP/s and the fraction of the dense bf16 peak, HIP events around 10 calls each."""
+    dt = torch.bfloat16
+    x = torch.randn(rows, D, device=device, dtype=dt)
+    w_uvqk = torch.randn(D, 4 * D, device=device, dtype=dt)
+    g_uvqk = torch.randn(rows, 4 * D, device=device, dtype=dt)
+    y3 = torch.randn(rows, 3 * D, device=device, dtype=dt)
+    w_out = torch.randn(3 * D, D, device=device, dtype=dt)
+    g_out = torch.randn(rows, D, device=device, dtype=dt)
+    cases = {
+        "uvqk_fwd": (lambda: torch.mm(x, w_uvqk), 2.0 * rows * D * 4 * D),
+        "uvqk_dgrad": (lambda: torch.mm(g_uvqk, w_uvqk.t()), 2.0 * rows * D * 4 * D),
+        "uvqk_wgrad": (lambda: torch.mm(x.t(), g_uvqk), 2.0 * rows * D * 4 * D),
+        "out_fwd": (lambda: torch.mm(y3, w_out), 2.0 * rows * 3 * D * D),
+        "out_dgrad": (lambda: torch.mm(g_out, w_out.t()), 2.0 * rows * 3 * D * D),
+        "out_wgrad": (lambda: torch.mm(y3.t(), g_out), 2.0 * rows * 3 * D * D),
+    }
+    res = {}
+    for name, (fn, flops) in cases.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tf = flops * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        res[name] = {"tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 3)}
+    return res
 
 
 def cpu_baseline(args):
@@ -183,7 +330,7 @@ def cpu_baseline(args):
     N, H, d = args.max_seq_len, args.heads, args.head_dim
     B = args.cpu_users
     gen = torch.Generator().manual_seed(1001)
-    lengths = make_lengths(args.workload if args.workload != "M-targets" else "M-jag", B, N, gen, "cpu")
+    lengths = make_lengths(args.workload if args.workload in ("M-full", "C2", "C3") else "M-jag", B, N, gen, "cpu")
     off = torch.zeros(B + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(lengths, 0)
     L = int(off[-1])
@@ -201,43 +348,125 @@ def cpu_baseline(args):
         times.append(time.perf_counter() - t0)
         q.grad = k.grad = v.grad = None
     med = statistics.median(times[1:])
+    res = dict(value=B / med, unit="user-seqs/s", cores=cores, kind="port",
+               sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of {len(times) - 1} passes "
+                      f"after 1 warm-up ({med * 1e3:.0f} ms each, {sum(times[1:]):.1f} s of CPU work); "
+                      f"oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
+    try:
+        res["layer"] = cpu_baseline_layer(args, cores)
+    except Exception as e:  # pragma: no cover
+        res["layer"] = {"error": repr(e)[:300]}
+    return res
+
+
+def cpu_baseline_layer(args, cores):
+    """3 STU layers (D=512, 4 heads of 128, group norm, targets) fwd+bwd with the reference's PyTorch-path algorithm on
+    the host cores (oracle/dense_torch.py::dense_stu_stack), fp32, 64 users of the layer section's length distribution"""
+    from oracle.dense_torch import dense_stu_stack
+
+    N, H, d = 200, 4, 128
+    D = H * d
+    B = 64
+    gen = torch.Generator().manual_seed(2002)
+    lengths = make_lengths("M-jag", B, N, gen, "cpu")
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lengths, 0)
+    L = int(off[-1])
+    layers = []
+    for _ in range(3):
+        prm = {"_input_norm_weight": torch.ones(D), "_input_norm_bias": torch.zeros(D),
+               "_uvqk_weight": torch.randn(D, 4 * D, generator=gen) * 0.02, "_uvqk_beta": torch.zeros(4 * D),
+               "_output_norm_weight": torch.ones(H), "_output_norm_bias": torch.zeros(H),
+               "_output_weight": torch.randn(3 * D, D, generator=gen) * 0.02}
+        for t in prm.values():
+            t.requires_grad_()
+        layers.append((prm, True))
+    x = torch.randn(L, D, generator=gen).requires_grad_()
+    gy = torch.randn(L, D, generator=gen)
+    nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen), lengths)
+    times = []
+    while len(times) < 2 or (sum(times[1:]) < 8.0 and len(times) < 21):
+        t0 = time.perf_counter()
+        y = dense_stu_stack(x, layers, num_heads=H, attn_dim=d, hidden_dim=d, max_seq_len=N, seq_offsets=off, num_targets=nt)
+        y.backward(gy)
+        times.append(time.perf_counter() - t0)
+        x.grad = None
+        for prm, _ in layers:
+            for t in prm.values():
+                t.grad = None
+    med = statistics.median(times[1:])
     return dict(value=B / med, unit="user-seqs/s", cores=cores, kind="port",
-                sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of {len(times) - 1} passes "
-                       f"after 1 warm-up ({med * 1e3:.0f} ms each, {sum(times[1:]):.1f} s of CPU work); "
-                       f"oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
+                sample=f"{B} users, 3 STU layers D=512 fp32 fwd+bwd, median of {len(times) - 1} passes after 1 warm-up "
+                       f"({med * 1e3:.0f} ms each); oracle/dense_torch.py::dense_stu_stack = reference modules/stu.py PyTorch path")
 
 
-def bwd_kernel_name(args) -> str:
-    """which backward kernel the library dispatches for this shape (csrc/attn_misc.hip: attn_bwd_fold_applicable)"""
-    fold = (args.head_dim in (64, 128) and (args.max_seq_len + 31) // 32 <= 7
-            and os.environ.get("HSTU_BWD_FOLD", "1")[:1] != "0")
-    return f"hstu_attn_bwd_{'fold_' if fold else ''}kernel<bf16,{args.head_dim},{args.head_dim}>"
+def attach_traffic(res, args, att):
+    """HBM bytes from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected with tools/prof_pmc.sh;
+    counters cannot be read from inside the process) -- attached only when the run's workload, users, head dim and
+    dtype are the ones the passes were taken on"""
+    res["roofline"]["traffic"] = None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            tr = json.load(open(path))
+        except Exception:
+            continue
+        src = tr.get("source", {"workload": "M-full", "users_per_gpu": 8192, "head_dim": 128, "heads": 4, "dtype": "bf16"})
+        same = (src.get("workload") == args.workload and src.get("users_per_gpu") == args.users_per_gpu
+                and src.get("head_dim") == args.head_dim and src.get("heads") == args.heads and src.get("dtype") == "bf16")
+        if not same:
+            continue
+        res["roofline"]["traffic"] = tr["bwd"]["hbm_bytes_per_launch"]
+        res["roofline"]["traffic_over_algorithmic"] = tr["bwd"]["hbm_bytes_per_launch"] / att["bwd_bytes"]
+        res["roofline"]["traffic_source"] = dict(file="profiles/" + name, kernel=tr["bwd"].get("kernel"), **src)
+        res["roofline_fwd"]["traffic"] = tr["fwd"]["hbm_bytes_per_launch"]
+        res["roofline_fwd"]["traffic_source"] = dict(file="profiles/" + name, kernel=tr["fwd"].get("kernel"), **src)
+        return
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="M-full", choices=["M-full", "M-jag", "M-targets"])
-    ap.add_argument("--users-per-gpu", type=int, default=8192)
-    ap.add_argument("--max-seq-len", type=int, default=200)
-    ap.add_argument("--heads", type=int, default=4)
-    ap.add_argument("--head-dim", type=int, default=128)
-    ap.add_argument("--layer-users-per-gpu", type=int, default=1024)
-    ap.add_argument("--layer-steps", type=int, default=10)
-    ap.add_argument("--cpu-users", type=int, default=128)
-    ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--no-layer", action="store_true")
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+def selftest_dist(args, rank, world):
+    """the N-rank scaffolding without the kernels (CPU, gloo): barrier-bracketed timing, MAX over ranks, the all-reduce
+    probe and the one-line JSON contract -- what tests/test_data_parallel.py runs with --gpus 2"""
+    from generative_recommenders_amd import data_parallel as dp
+
+    device = torch.device("cpu")
+    x = torch.randn(256, 256)
+    for _ in range(args.warmup):
+        x = torch.tanh(x @ x.t() / 256)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = torch.tanh(x @ x.t() / 256)
+    if world > 1:
+        dist.barrier()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0, device)
+    res = {"metric": "selftest (no kernels)", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "selftest"},
+           "selftest": True, "rccl": rccl_section(world, device, nbytes=1 << 20),
+           "ranks_seen": int(dp.sum_over_ranks(1.0, device))}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+def run(args):
+    from generative_recommenders_amd import data_parallel as dp
+
+    if args.selftest_dist:
+        rank, local_rank, world = dp.init_from_env(backend="gloo")
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        selftest_dist(args, rank, world)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     from generative_recommenders_amd import _lib
-    from generative_recommenders_amd import data_parallel as dp
 
     rank, local_rank, world = dp.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HSTU ops are HIP kernels with no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()     # (== local_rank on a node with one GPU per rank)
@@ -247,8 +476,10 @@ def main():
 
     att = attention_section(args, rank, world, device)
     value = world * att["users"] * args.steps / att["elapsed"]
+    N, H, d = args.max_seq_len, args.heads, args.head_dim
+    what = "fwd" if att["fwd_only"] else "fwd+bwd"
     res = {
-        "metric": "user-seqs/sec (fwd+bwd) HSTU attention L=200 d=512",
+        "metric": f"user-seqs/sec ({what}) HSTU attention L={N} d={H * d}",
         "value": value,
         "unit": "user-seqs/s",
         "n_gpus": world,
@@ -261,63 +492,100 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {args.users_per_gpu} users/GPU, L<= {args.max_seq_len}, H={args.heads}, "
-                        f"dqk=dv={args.head_dim}, q/k/v strided views of one fused buffer, attention fwd+bwd via C ABI",
+            "workload": f"{args.workload}: {args.users_per_gpu} users/GPU, L<= {N}, H={H}, dqk=dv={d}; {WORKLOADS[args.workload][4]}; "
+                        f"attention {what} via the C ABI" + ("" if args.workload in ("C2", "C5") else ", q/k/v strided views of one fused buffer"),
             "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "parallelism": f"dp{world} (no collective: attention has no parameters)",
         },
-        "roofline": {
-            "bound": "hbm", "kernel": bwd_kernel_name(args),
-            "achieved": att["bwd_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att["bwd_gbps"] / HBM_PEAK_GBPS,
-            "traffic": None, "algorithmic_bytes_per_launch": att["bwd_bytes"], "avg_launch_ms": att["bwd_ms"],
-        },
-        "roofline_fwd": {
-            "bound": "hbm", "kernel": "hstu_attn_fwd_kernel<bf16,128,128>", "achieved": att["fwd_gbps"],
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att["fwd_gbps"] / HBM_PEAK_GBPS,
-            "algorithmic_bytes_per_launch": att["fwd_bytes"], "avg_launch_ms": att["fwd_ms"],
-        },
-        "roofline_fwd_bwd": {"achieved": att["both_gbps"], "unit": "GB/s", "frac": att["both_gbps"] / HBM_PEAK_GBPS,
-                             "tflops_causal_model": att["tflops"]},
+        "device_ms_per_step": att["device_ms_per_step"],
     }
-    # HBM traffic from the PMC passes (collected separately with tools/prof_pmc.sh on this same
-    # workload and committed under profiles/; counters cannot be read from inside the process)
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.workload == "M-full" and args.users_per_gpu == 8192:
-            res["roofline"]["traffic"] = tr["bwd"]["hbm_bytes_per_launch"]
-            res["roofline"]["traffic_over_algorithmic"] = tr["bwd"]["hbm_bytes_per_launch"] / att["bwd_bytes"]
-            res["roofline_fwd"]["traffic"] = tr["fwd"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    # what a pure streaming kernel of the same read:write mix reaches on this part (tools/membench, measured separately
-    # and committed): context for `frac`, which stays relative to the 8 TB/s vendor peak
-    try:
-        mb = json.load(open(os.path.join(ROOT, "profiles", "r01_membench_2.json")))
-        best = lambda key: max(v for k, v in mb.items() if k.startswith(key + "_g"))
-        res["roofline"]["streaming_4r3w_GBps"] = best("r4w3")
-        res["roofline"]["frac_of_streaming_4r3w"] = att["bwd_gbps"] / best("r4w3")
-        res["roofline_fwd"]["streaming_3r1w_GBps"] = best("r3w1")
-        res["roofline_fwd"]["frac_of_streaming_3r1w"] = att["fwd_gbps"] / best("r3w1")
-    except Exception:
-        pass
+    dom = "fwd" if att["fwd_only"] else "bwd"
+    res["roofline"] = {
+        "bound": "hbm", "kernel": att["kernels"][dom],
+        "achieved": att[dom + "_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att[dom + "_gbps"] / HBM_PEAK_GBPS,
+        "traffic": None, "algorithmic_bytes_per_launch": att[dom + "_bytes"], "avg_launch_ms": att[dom + "_ms"],
+    }
+    res["roofline_fwd"] = {
+        "bound": "hbm", "kernel": att["kernels"]["fwd"], "achieved": att["fwd_gbps"],
+        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att["fwd_gbps"] / HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_launch": att["fwd_bytes"], "avg_launch_ms": att["fwd_ms"],
+    }
+    res["roofline_fwd_bwd"] = {"achieved": att["both_gbps"], "unit": "GB/s", "frac": att["both_gbps"] / HBM_PEAK_GBPS,
+                               "tflops_causal_model": att["tflops"]}
+    attach_traffic(res, args, att)
     if rank == 0:
         try:
             res["measured_copy_GBps"] = copy_bandwidth(device)
         except Exception as e:  # pragma: no cover
             res["measured_copy_GBps"] = f"error: {e}"
+    if world > 1:
+        try:
+            res["rccl"] = rccl_section(world, device)
+        except Exception as e:  # pragma: no cover
+            res["rccl"] = {"error": repr(e)[:300]}
     if not args.no_layer:
         try:
             res["layer"] = layer_section(args, rank, world, device)
         except Exception as e:  # the headline number must survive a failure of the secondary section
             res["layer"] = {"error": repr(e)[:300]}
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
         try:
             res["cpu_baseline"] = cpu_baseline(args)
         except Exception as e:  # pragma: no cover
             res["cpu_baseline"] = {"error": repr(e)[:300]}
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawned(local_rank, args, port):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(args.gpus),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run(args)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="M-full", choices=sorted(WORKLOADS))
+    ap.add_argument("--users-per-gpu", type=int, default=None)
+    ap.add_argument("--max-seq-len", type=int, default=None)
+    ap.add_argument("--heads", type=int, default=None)
+    ap.add_argument("--head-dim", type=int, default=None)
+    ap.add_argument("--layer-users-per-gpu", type=int, default=1024)
+    ap.add_argument("--layer-steps", type=int, default=10)
+    ap.add_argument("--cpu-users", type=int, default=128)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--no-layer", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--selftest-dist", action="store_true", help="CPU / gloo run of the N-rank scaffolding only (tests)")
+    args = ap.parse_args()
+    n, h, d, users, _ = WORKLOADS[args.workload]
+    args.max_seq_len = args.max_seq_len or n
+    args.heads = args.heads or h
+    args.head_dim = args.head_dim or d
+    args.users_per_gpu = args.users_per_gpu or users
+    if args.workload == "C5":
+        args.no_layer = True       # the long-history workload has its own memory budget
+    if args.workload.startswith("C"):   # the secondary sections belong to the metric shape
+        args.no_layer = args.no_cpu = True
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks here (reference: main.py:68-78 mp.start_processes)
+        import torch.multiprocessing as mp
+
+        mp.spawn(_spawned, args=(args, _free_port()), nprocs=args.gpus, join=True)
+        return
+    run(args)
 
 
 if __name__ == "__main__":

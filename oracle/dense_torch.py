@@ -67,3 +67,33 @@ def dense_hstu_mha(max_seq_len: int, alpha: float, q: torch.Tensor, k: torch.Ten
     B = lengths.numel()
     keep = (torch.arange(n).view(1, n) < lengths.clamp(max=n).view(B, 1)).view(-1)
     return dense.reshape(B * n, H, v.shape[2])[keep]
+
+
+def dense_stu_layer(x: torch.Tensor, p: dict, num_heads: int, attn_dim: int, hidden_dim: int, max_seq_len: int,
+                    seq_offsets: torch.Tensor, num_targets: Optional[torch.Tensor], group_norm: bool,
+                    attn_alpha: Optional[float] = None, eps: float = 1e-6) -> torch.Tensor:
+    """One STULayer forward on CPU with the reference's PyTorch-path algorithm (modules/stu.py:291-352):
+    layer norm -> addmm(uvqk) -> split u|v|q|k, SiLU(u) (ops/hstu_compute.py:50-89) -> padded-dense attention (above)
+    -> u * LN|GN(attn), concat [u, attn, y] (ops/pytorch/pt_hstu_linear.py:22-66) -> addmm(x, y, W_o) (:68-99).
+    ``p`` holds the layer's parameters under the reference's names (``_input_norm_weight`` ...).  Backward is autograd."""
+    H, A, Hd = num_heads, attn_dim, hidden_dim
+    normed = F.layer_norm(x, (x.shape[1],), p["_input_norm_weight"], p["_input_norm_bias"], eps)
+    uvqk = torch.addmm(p["_uvqk_beta"], normed, p["_uvqk_weight"])
+    u, v, q, k = torch.split(uvqk, [Hd * H, Hd * H, A * H, A * H], dim=1)
+    u = F.silu(u)
+    alpha = attn_alpha if attn_alpha is not None else 1.0 / (A**0.5)
+    attn = dense_hstu_mha(max_seq_len, alpha, q.reshape(-1, H, A), k.reshape(-1, H, A), v.reshape(-1, H, Hd), seq_offsets,
+                          num_targets).reshape(-1, H * Hd)
+    if group_norm:
+        y = u * F.group_norm(attn.view(-1, H, Hd), num_groups=H, weight=p["_output_norm_weight"], bias=p["_output_norm_bias"],
+                             eps=eps).view(-1, H * Hd)
+    else:
+        y = u * F.layer_norm(attn, (H * Hd,), p["_output_norm_weight"], p["_output_norm_bias"], eps)
+    return torch.addmm(x, torch.cat([u, attn, y], dim=1), p["_output_weight"])
+
+
+def dense_stu_stack(x: torch.Tensor, layers: list, **kw) -> torch.Tensor:
+    """STUStack: the layers one after the other (modules/stu.py:421-466); ``layers`` = list of (params, group_norm)"""
+    for prm, gn in layers:
+        x = dense_stu_layer(x, prm, group_norm=gn, **kw)
+    return x

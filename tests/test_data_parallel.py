@@ -90,3 +90,40 @@ def test_sharded_attention_equals_the_full_batch():
             np.testing.assert_array_equal(sq, dq[rows])
             np.testing.assert_array_equal(sk, dk[rows])
             np.testing.assert_array_equal(sv, dv[rows])
+
+
+def _last_json_line(text):
+    import json
+
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_spawns_its_own_ranks_and_under_torchrun_on_gloo():
+    """`python bench.py --gpus 2` without a launcher spawns its two ranks itself (reference: main.py:68-78); under
+    torch.distributed.run it takes them from the environment.  --selftest-dist runs the N-rank scaffolding only (barriers,
+    MAX over ranks, the all-reduce probe, ONE JSON line from rank 0) on CPU / gloo."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    base = [os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-dist", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run([sys.executable] + base, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo"
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["ms_per_step"] > 0 and d["rccl"]["busbw_GBps"] > 0
+    assert sum(1 for ln in r.stdout.splitlines() if ln.startswith("{")) == 1          # rank 0 only
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29547"] + base, cwd=root, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    # a launcher / flag mismatch is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-dist"], cwd=root,
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -187,6 +187,27 @@ def test_mask_zero_history_and_properties():
     assert m[7, :6].all() and m[7, 7] and not m[7, 6]
 
 
+def test_dense_torch_stu_stack_matches_reference():
+    """the CPU port bench.py times as the layer baseline (oracle/dense_torch.py::dense_stu_stack) against the reference's
+    2-layer STUStack (layer norm + group norm layers, targets), forward and input gradient"""
+    import torch
+
+    from oracle.dense_torch import dense_stu_stack
+
+    c = load_cases("stu.npz")[0]
+    layers = []
+    for li, gn in enumerate((False, True)):
+        prm = {k.split(".")[-1]: torch.from_numpy(v) for k, v in c.items() if k.startswith(f"p:_stu_layers.{li}.")}
+        layers.append((prm, gn))
+    x = torch.from_numpy(c["x"]).requires_grad_()
+    y = dense_stu_stack(x, layers, num_heads=int(c["H"]), attn_dim=int(c["A"]), hidden_dim=int(c["Hd"]),
+                        max_seq_len=int(c["N"]), seq_offsets=torch.from_numpy(c["offsets"]),
+                        num_targets=torch.from_numpy(c["num_targets"]))
+    np.testing.assert_allclose(y.detach().numpy(), c["y"], rtol=1e-4, atol=1e-5)
+    y.backward(torch.from_numpy(c["gy"]))
+    np.testing.assert_allclose(x.grad.numpy(), c["dx"], rtol=1e-4, atol=1e-5)
+
+
 def _bf16_bits_to_f64(bits):
     import torch
 
