@@ -43,6 +43,7 @@ class HstuAttnParams(C.Structure):
         ("dtype", C.c_int32), ("offsets_dtype", C.c_int32), ("targets_dtype", C.c_int32),
         ("pos_w", C.c_void_p), ("ts_w", C.c_void_p), ("timestamps", C.c_void_p),
         ("ts_row_stride", C.c_int64), ("num_buckets", C.c_int32), ("bucket_div", C.c_float),
+        ("attn_scale", C.c_void_p),
     ]
 
 
@@ -108,7 +109,31 @@ def build(verbose: bool = False) -> str:
         print(res.stderr[-4000:])
     if res.returncode != 0:
         raise HstuLibraryError("building libhstu_hip.so failed (see output above)")
+    build_torch_ops(verbose)
     return LIB_PATH
+
+
+def build_torch_ops(verbose: bool = False) -> str:
+    """Compile libhstu_torch_ops.so: host-side C++ (no device code) that registers the ``hstu::`` torch.library schemas
+    with CUDA + Meta kernels on top of the C ABI (csrc/torch_ops/hstu_torch_ops.cpp).  Skipped when up to date."""
+    src = os.path.join(_HERE, "csrc", "torch_ops", "hstu_torch_ops.cpp")
+    out = os.path.join(_HERE, "libhstu_torch_ops.so")
+    deps = [src, os.path.join(_HERE, "..", "include", "hstu_hip.h")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    tdir = os.path.dirname(torch.__file__)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include", src, "-o", out,
+           f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", f"-L{_HERE}", "-lhstu_hip",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir}/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise HstuLibraryError("building libhstu_torch_ops.so failed (see output above)")
+    return out
 
 
 def lib() -> C.CDLL:

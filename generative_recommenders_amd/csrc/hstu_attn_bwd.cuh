@@ -290,7 +290,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   __syncthreads();
   HSTU_MARK(3);
 
-  const float ds_scale = p.scale * p.alpha;
+  const float scale_v = attn_scale_of(p);
+  const float ds_scale = scale_v * p.alpha;
   const int key = k0w + n32;
   const bool key_ok = tile_owner && key < len;
   const int key_id = mc.id_of(key);
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         const float* cp = hts + (i - npos) * ts_copies;
         for (int c = 0; c < ts_copies; ++c) v += cp[c];
       }
-      row[i] = v * p.scale;
+      row[i] = v * scale_v;
     }
   }
   // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv.  16-bit I/O with the
@@ -568,8 +569,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         for (int d = 0; d < C::DBV; ++d)
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
-            u32x2 v = {E::pk2(dv_acc[d][4 * rq] * p.scale, dv_acc[d][4 * rq + 1] * p.scale),
-                       E::pk2(dv_acc[d][4 * rq + 2] * p.scale, dv_acc[d][4 * rq + 3] * p.scale)};
+            u32x2 v = {E::pk2(dv_acc[d][4 * rq] * scale_v, dv_acc[d][4 * rq + 1] * scale_v),
+                       E::pk2(dv_acc[d][4 * rq + 2] * scale_v, dv_acc[d][4 * rq + 3] * scale_v)};
             *LDS_PTR(u32x2, vt + tile_off<C::UPR_V>(n32, 4 * d + rq) + 8 * hf) = v;
           }
         const int rows_valid = len - k0w;
@@ -611,8 +612,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         for (int rq = 0; rq < 4; ++rq) {
           const int d0 = 32 * d + 8 * rq + 4 * hf;
           if (d0 < p.dv)
-            store4<T>(dvrow, d0, dv_acc[d][4 * rq] * p.scale, dv_acc[d][4 * rq + 1] * p.scale, dv_acc[d][4 * rq + 2] * p.scale,
-                      dv_acc[d][4 * rq + 3] * p.scale);
+            store4<T>(dvrow, d0, dv_acc[d][4 * rq] * scale_v, dv_acc[d][4 * rq + 1] * scale_v, dv_acc[d][4 * rq + 2] * scale_v,
+                      dv_acc[d][4 * rq + 3] * scale_v);
         }
     }
 }

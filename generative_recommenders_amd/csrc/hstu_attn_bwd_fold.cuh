@@ -458,7 +458,8 @@ HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int to
   for (int d = 0; d < C::DBV; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv_acc[d][r] = 0.f;
-  const float ds_scale = p.scale * p.alpha;
+  const float scale_v = attn_scale_of(p);
+  const float ds_scale = scale_v * p.alpha;
 
   // lane-constant mask patterns of the plain-causal case (see fold_pair): low half = diagonal tile, bit r set iff
   // key n32 <= query row (r&3) + 8 (r>>2) + 4 hf; high half = last query tile, bit r set iff that row is < len
@@ -528,7 +529,7 @@ HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int to
       // other waves' dQ GEMM: dK follows after the next barrier.
       int lane3 = lane;
       asm volatile("" : "+v"(lane3));
-      fold_park_tile<T, DV>(dv_acc, p.scale, smem + wave * C::PAIR + C::KT, lane3);
+      fold_park_tile<T, DV>(dv_acc, scale_v, smem + wave * C::PAIR + C::KT, lane3);
 #pragma unroll
       for (int d = 0; d < C::DBV; ++d)
 #pragma unroll
@@ -577,7 +578,7 @@ HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int to
   }
   if (b_fin) {
     fold_add<C::DBV>(dv_acc, reg_a, lane4);
-    fold_park_tile<T, DV>(dv_acc, p.scale, reg_a + C::KT, lane4);
+    fold_park_tile<T, DV>(dv_acc, scale_v, reg_a + C::KT, lane4);
   }
   __syncthreads();
   HSTU_MARK(24);

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   if (q0 >= nq_rows) return;
 
   const MaskCtx mc = make_mask_ctx(p, b, len);
+  const float scale_v = attn_scale_of(p);
 #ifdef HSTU_TRACE
   HSTU_TRACE_DECL(g_hstu_trace_fwd, g_hstu_trace_fwd != nullptr && blockIdx.x == 4096);
 #endif
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         for (int d = 0; d < C::DB; ++d)
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
-            u32x2 v = {E::pk2(oacc[d][4 * rq] * p.scale, oacc[d][4 * rq + 1] * p.scale),
-                       E::pk2(oacc[d][4 * rq + 2] * p.scale, oacc[d][4 * rq + 3] * p.scale)};
+            u32x2 v = {E::pk2(oacc[d][4 * rq] * scale_v, oacc[d][4 * rq + 1] * scale_v),
+                       E::pk2(oacc[d][4 * rq + 2] * scale_v, oacc[d][4 * rq + 3] * scale_v)};
             *LDS_PTR(u32x2, tile + tile_off<C::UPR_V>(n32, 4 * d + rq) + 8 * hf) = v;
           }
         char* obase = (char*)p.out + ((q_base + r0) * p.o_row_stride + (int64_t)hd * p.o_head_stride) * C::EB;
@@ -403,8 +404,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       for (int rq = 0; rq < 4; ++rq) {
         const int d0 = 32 * d + 8 * rq + 4 * hf;
         if (d0 < p.dv)
-          store4<T>(orow, d0, oacc[d][4 * rq] * p.scale, oacc[d][4 * rq + 1] * p.scale, oacc[d][4 * rq + 2] * p.scale,
-                    oacc[d][4 * rq + 3] * p.scale);
+          store4<T>(orow, d0, oacc[d][4 * rq] * scale_v, oacc[d][4 * rq + 1] * scale_v, oacc[d][4 * rq + 2] * scale_v,
+                    oacc[d][4 * rq + 3] * scale_v);
       }
     }
   }

@@ -385,6 +385,9 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
   return c;
 }
 
+// 1/N, or the caller's device-side replacement for it (HstuAttnParams::attn_scale: the reference's attn_scale[0])
+HSTU_DEV float attn_scale_of(const HstuAttnParams& p) { return p.attn_scale ? *p.attn_scale : p.scale; }
+
 // silu(s) = s * sigmoid(s), fp32, hardware exp2 / rcp (1 ulp each)
 HSTU_DEV float fast_sigmoid(float s) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * s));

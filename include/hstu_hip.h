@@ -93,6 +93,10 @@ typedef struct HstuAttnParams {
   int64_t ts_row_stride;
   int32_t num_buckets;         /* 128 in every shipped config */
   float bucket_div;            /* 0.301 */
+  /* optional: device pointer to ONE float that replaces `scale` (read by the kernels at launch time, no host
+   * sync) -- the reference's `attn_scale` tensor, of which its kernels use element 0 (flash_api.cpp:283,
+   * mainloop_fwd_sm80.h:790-793, mainloop_bwd_sm80.h:892-894).  NULL: `scale` is used. */
+  const float* attn_scale;
 } HstuAttnParams;
 
 /*

@@ -236,3 +236,37 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert out.returncode == 0 and out.stdout.strip() == str(_lib.ABI_VERSION), (out.stdout, out.stderr)
+
+
+def test_compiled_operator_library_registers_schemas_and_meta_kernels():
+    """libhstu_torch_ops.so: torch.ops.load_library() alone yields the reference's hstu:: schemas (argument for argument:
+    flash_api.cpp:275-352, cpp_ops.cpp:94-102) with Meta kernels for every operator (shape inference on the CPU box);
+    CPU tensors are refused by the dispatcher (no CPU kernels, no fallback)."""
+    import pytest
+    import torch
+
+    from generative_recommenders_amd.ops import torch_library
+
+    torch_library.register()
+    torch_library.register()
+    s = str(torch.ops.hstu.hstu_mha_bwd.default._schema)
+    assert s == ("hstu::hstu_mha_bwd(int max_seq_len, float alpha, Tensor dout, Tensor q, Tensor k, Tensor v, Tensor dq, Tensor dk, "
+                 "Tensor dv, Tensor? seq_offsets, bool causal, Tensor? num_targets, Tensor? attn_scale, int max_attn_len, "
+                 "int min_full_attn_seq_len, int contextual_seq_len, bool sort_by_length, bool deterministic, int sm_margin) -> Tensor[]")
+    assert "SymInt max_seq_len, float alpha, Tensor q, Tensor k, Tensor v, Tensor? seq_offsets, bool causal" in str(
+        torch.ops.hstu.hstu_mha.default._schema)
+    m = lambda *shape, dtype=torch.bfloat16: torch.empty(*shape, dtype=dtype, device="meta")
+    q, v, off = m(10, 2, 16), m(10, 2, 24), m(3, dtype=torch.int64)
+    assert torch.ops.hstu.hstu_mha(20, 0.25, q, q, v, off, True, None, None, 0, 0, 0, None, None, None, False, False, 0).shape == (10, 2, 24)
+    assert torch.ops.hstu.hstu_mha_fwd(20, 0.25, m(3, 20, 2, 16), m(3, 20, 2, 16), m(3, 20, 2, 24), None, True, None, None, 0, 0, 0,
+                                       None, None, None, 0).shape == (3, 20, 2, 24)
+    grads = torch.ops.hstu.hstu_mha_bwd(20, 0.25, v, q, q, v, m(10, 2, 16), m(10, 2, 16), m(10, 2, 24), off, True, None, None, 0, 0, 0,
+                                        False, False, 0)
+    assert [tuple(g.shape) for g in grads] == [(10, 2, 16), (10, 2, 16), (10, 2, 24)]
+    i64 = lambda n: m(n, dtype=torch.int64)
+    assert torch.ops.hstu.complete_cumsum(i64(5)).shape == (6,)
+    assert torch.ops.hstu.expand_1d_jagged_to_dense(i64(7), off, 4).shape == (2, 4)
+    assert torch.ops.hstu.concat_1d_jagged_jagged(i64(2), i64(7), i64(2), i64(5)).shape == (12,)
+    assert [tuple(t.shape) for t in torch.ops.hstu.sort_kv_pairs(i64(6), i64(6))] == [(6,), (6,)]
+    with pytest.raises((RuntimeError, NotImplementedError), match="CPU"):
+        torch.ops.hstu.complete_cumsum(torch.arange(4))

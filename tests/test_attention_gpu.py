@@ -386,11 +386,25 @@ def test_torch_library_operator_seam():
     x = torch.tensor([3, 0, 5], device=DEV)
     assert torch.ops.hstu.complete_cumsum(x).tolist() == [0, 3, 3, 8]
     assert torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach().to("meta"), k.detach().to("meta"),
-                                       v.detach().to("meta"), None, True, None, None, 0, 0, 0, None, None, None,
+                                       v.detach().to("meta"), off.to("meta"), True, None, None, 0, 0, 0, None, None, None,
                                        0).shape == ref.shape
-    with pytest.raises(RuntimeError, match="attn_scale"):
-        torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach(), k.detach(), v.detach(), off, True, nt,
-                                    torch.ones(1, device=DEV), 0, 0, 0, None, None, None, 0)
+    # attn_scale: element 0 replaces 1/N, read on the device (flash_api.cpp:283, mainloop_fwd_sm80.h:790-793)
+    o3 = torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach(), k.detach(), v.detach(), off, True, nt,
+                                     torch.full((1,), 2.0 / c["N"], device=DEV), c["w"], 0, 0, None, None, None, 0)
+    assert torch.equal(o3, 2 * ref)
+    with pytest.raises(RuntimeError, match="fp8"):
+        torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach(), k.detach(), v.detach(), off, True, nt, None, 0, 0, 0,
+                                    torch.ones(1, device=DEV), None, None, 0)
+    # dense (B, S, H, d) inputs without offsets == jagged inputs with every length S (flash_common.cpp dense branch)
+    B, S, H, d = 3, 40, 2, 32
+    qd, kd, vd = (torch.randn(B, S, H, d, device=DEV, dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+    od = torch.ops.hstu.hstu_mha(S, 0.2, qd, kd, vd, None, True, None, None, 0, 0, 0, None, None, None, False, False, 0)
+    offs = torch.arange(B + 1, device=DEV) * S
+    oj = _ops().hstu_mha(S, 0.2, qd.detach().reshape(B * S, H, d), kd.detach().reshape(B * S, H, d),
+                         vd.detach().reshape(B * S, H, d), offs)
+    assert od.shape == (B, S, H, d) and torch.equal(od.reshape(B * S, H, d), oj)
+    od.sum().backward()
+    assert qd.grad is not None and qd.grad.shape == qd.shape and torch.isfinite(qd.grad.float()).all()
 
 
 # ------------------------------------------------------------------ folded backward schedule (short sequences, d in {64, 128})
