@@ -1,7 +1,7 @@
 // Launcher of the folded backward schedule (hstu_attn_bwd_fold.cuh).
 #pragma once
 #include "capi_internal.h"
-#include "hstu_attn_bwd_fold.cuh"
+#include "hstu_attn_bwd_quad.cuh"
 
 namespace hstu {
 
@@ -25,9 +25,30 @@ static int launch_bwd_fold_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   return check_launch("hstu_attn_bwd(fold)");
 }
 
+// head dim 64: 4-wave workgroups, two per CU (hstu_attn_bwd_quad.cuh)
+template <typename T, int D>
+static int launch_bwd_quad_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
+  using Q = QuadCfg<T, D>;
+  const HstuAttnParams& p = bp.fwd;
+  const int tmax = (p.max_seq_len + 31) / 32;
+  const int smem = Q::smem_bytes();
+  static_assert(Q::smem_bytes() <= 80 * 1024, "two workgroups per CU");
+  auto kern = hstu_attn_bwd_quad_kernel<T, D>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+  int grid = p.batch * p.heads;
+  if (QUAD_PERSIST) {
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    if (grid > 2 * n_cu) grid = 2 * n_cu;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kQuadThreads), smem, st, bp, tmax);
+  return check_launch("hstu_attn_bwd(quad)");
+}
+
 template <typename T>
 static int launch_bwd_fold_dtype(const HstuAttnBwdParams& bp, hipStream_t st) {
   if (bp.fwd.dqk == 128) return launch_bwd_fold_inst<T, 128>(bp, st);
+  if (bp.fwd.dqk == 64 && attn_bwd_quad_applicable(bp)) return launch_bwd_quad_inst<T, 64>(bp, st);
   if (bp.fwd.dqk == 64) return launch_bwd_fold_inst<T, 64>(bp, st);
   return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd(fold): head dim %d not instantiated", bp.fwd.dqk);
 }

@@ -33,6 +33,11 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 
+bool attn_bwd_quad_applicable(const HstuAttnBwdParams& bp) {
+  static const bool enabled = [] { const char* e = getenv("HSTU_BWD_QUAD"); return !(e && e[0] == '0'); }();
+  return enabled && attn_bwd_fold_applicable(bp) && bp.fwd.dqk == 64;
+}
+
 // Name of the instantiation attn_launch.cuh / attn_fold.cuh dispatch (the same decisions, restated once here; the
 // launch tests compare it with the kernel names rocprofv3 reports).
 int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char* buf, size_t len) {
@@ -41,7 +46,8 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   const int a = pad_head_dim(p.dqk), v = pad_head_dim(p.dv);
   if (a == 0 || v == 0) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "head dims (%d, %d) not instantiated", p.dqk, p.dv); }
   if (p.pos_w && a != v) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "relative-bias attention is instantiated for dqk == dv"); }
-  if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
+  if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
+  else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
   else snprintf(buf, len, "hstu_attn_%s_kernel<%s,%d,%d%s>", bwd ? "bwd" : "fwd", dt, a, v, p.pos_w ? ",bias" : "");
   return HSTU_OK;
 }

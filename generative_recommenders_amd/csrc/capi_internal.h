@@ -25,6 +25,8 @@ int launch_attn_bwd_bias_f32(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_bf16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_f16(const HstuAttnBwdParams& p, hipStream_t st);
 bool attn_bwd_fold_applicable(const HstuAttnBwdParams& p);
+// ... and, among those, the ones the 4-wave / two-workgroups-per-CU kernel takes (head dim 64; HSTU_BWD_QUAD=0 disables)
+bool attn_bwd_quad_applicable(const HstuAttnBwdParams& p);
 // sums the per-workgroup bias-gradient rows: partial (rows, width) -> dpos_w (npos), dts_w (width - npos)
 int launch_bias_grad_reduce(const float* partial, int rows, int width, int npos, float* dpos_w, float* dts_w,
                             hipStream_t st);
