@@ -453,6 +453,11 @@ def selftest_dist(args, rank, world):
 def run(args):
     from generative_recommenders_amd import data_parallel as dp
 
+    if os.environ.get("HSTU_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["HSTU_BENCH_WATCHDOG"]), exit=True)
+
     if args.selftest_dist:
         rank, local_rank, world = dp.init_from_env(backend="gloo")
         if world != args.gpus:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel roofline table for the HBM-bound helper kernels of the path: algorithmic
-bytes / HIP-event time vs the 8 TB/s HBM peak, at the DLRM-v3 layer shape (1024 users, L ~ U[180,200), D = 512, bf16).
+bytes / HIP-event time vs the 8 TB/s HBM peak, at the DLRM-v3 layer shape (1024 users -- or argv[1] -- L ~ U[180,200), D = 512, bf16).
 Prints one JSON object (also the torch CPU time of the same op on a bounded sample, as the CPU leg).
 Run on the GPU box:  python tools/bench_ops.py > gpurun_out/bench_ops.json"""
 import json, os, sys, time
@@ -12,7 +12,7 @@ from generative_recommenders_amd.ops import _launch
 PEAK = 8000.0
 dev = "cuda"
 torch.manual_seed(0)
-B, N, D, H = 1024, 200, 512, 4
+B, N, D, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 200, 512, 4   # 8192 users: every working set is far beyond the 256 MiB Infinity Cache
 lengths = torch.randint(180, 200, (B,), device=dev)
 off = _launch.complete_cumsum(lengths)
 L = int(off[-1])
