@@ -147,11 +147,14 @@ def attention_section(args, rank, world, device):
         dfused = torch.empty_like(fused)
         dq, dk, dv = torch.split(dfused, [d, d, d], dim=-1)
 
+        # sort_by_length (reference default for the layer): workgroups take the users heaviest first
+        order = _launch.length_order(off) if args.sort_by_length else None
+
         def fwd():
-            return _launch.attn_fwd(q, k, v, off, nt, N, alpha, 1.0 / N)
+            return _launch.attn_fwd(q, k, v, off, nt, N, alpha, 1.0 / N, user_order=order)
 
         def bwd():
-            return _launch.attn_bwd(dout, q, k, v, off, nt, N, alpha, 1.0 / N, dq=dq, dk=dk, dv=dv)
+            return _launch.attn_bwd(dout, q, k, v, off, nt, N, alpha, 1.0 / N, dq=dq, dk=dk, dv=dv, user_order=order)
 
         fwd_bytes = L * H * (2 * d + 2 * d) * es
         bwd_bytes = L * H * (4 * d + 3 * d) * es
@@ -499,7 +502,7 @@ def run(args):
         "config": {
             "workload": f"{args.workload}: {args.users_per_gpu} users/GPU, L<= {N}, H={H}, dqk=dv={d}; {WORKLOADS[args.workload][4]}; "
                         f"attention {what} via the C ABI" + ("" if args.workload in ("C2", "C5") else ", q/k/v strided views of one fused buffer"),
-            "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "parallelism": f"dp{world} (no collective: attention has no parameters)",
+            "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "sort_by_length": args.sort_by_length, "parallelism": f"dp{world} (no collective: attention has no parameters)",
         },
         "device_ms_per_step": att["device_ms_per_step"],
     }
@@ -571,6 +574,7 @@ def main():
     ap.add_argument("--layer-steps", type=int, default=10)
     ap.add_argument("--cpu-users", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--sort-by-length", type=int, default=None, help="1: heavy-first workgroup order (default: on for C3)")
     ap.add_argument("--no-layer", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU / gloo run of the N-rank scaffolding only (tests)")
@@ -580,6 +584,7 @@ def main():
     args.heads = args.heads or h
     args.head_dim = args.head_dim or d
     args.users_per_gpu = args.users_per_gpu or users
+    args.sort_by_length = bool(args.sort_by_length) if args.sort_by_length is not None else args.workload == "C3"
     if args.workload == "C5":
         args.no_layer = True       # the long-history workload has its own memory budget
     if args.workload.startswith("C"):   # the secondary sections belong to the metric shape

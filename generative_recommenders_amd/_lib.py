@@ -43,7 +43,7 @@ class HstuAttnParams(C.Structure):
         ("dtype", C.c_int32), ("offsets_dtype", C.c_int32), ("targets_dtype", C.c_int32),
         ("pos_w", C.c_void_p), ("ts_w", C.c_void_p), ("timestamps", C.c_void_p),
         ("ts_row_stride", C.c_int64), ("num_buckets", C.c_int32), ("bucket_div", C.c_float),
-        ("attn_scale", C.c_void_p),
+        ("attn_scale", C.c_void_p), ("user_order", C.c_void_p),
     ]
 
 

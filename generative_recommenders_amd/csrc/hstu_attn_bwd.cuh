@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int kb = rem / 8;
   const int uh = grp * 8 + (rem & 7);
   if (uh >= p.batch * p.heads) return;
-  const int b = uh / p.heads, hd = uh % p.heads;
+  const int b = user_of_slot(p, uh / p.heads), hd = uh % p.heads;
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
   const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
   const int kb0 = kb * 32 * nw;

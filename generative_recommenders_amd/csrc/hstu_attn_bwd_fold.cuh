@@ -393,7 +393,7 @@ HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int to
   static_assert(DQK / 32 <= 4, "dQ GEMM: 32 feature columns x 16 query rows per wave");
   static_assert(DQK == DV, "hand-over regions assume equal K and V tile sizes");
   const HstuAttnParams& p = bp.fwd;
-  const int b = ((FOLD_ABLATE & 128) ? uh % 256 : (FOLD_ABLATE & 256) ? uh % 32 : uh) / p.heads, hd = uh % p.heads;   // 128 / 256: every problem aliases one of the first 256 / 32 (cache-resident data)
+  const int b = user_of_slot(p, ((FOLD_ABLATE & 128) ? uh % 256 : (FOLD_ABLATE & 256) ? uh % 32 : uh) / p.heads), hd = uh % p.heads;   // 128 / 256: every problem aliases one of the first 256 / 32 (cache-resident data)
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
   // A user longer than max_seq_len is a caller error (the reference's padded path would truncate it to N rows); the
   // kernel stays inside its 7 K/V slots: rows past 32 * tmax are ignored (their gradient rows are not written).
@@ -403,7 +403,7 @@ HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int to
   if (len <= 0) return;
   // the problem this workgroup takes next (persistent launch): its offsets are loaded now, its K/V tiles of the slots
   // that are free during this problem's tail are issued there
-  const int b3 = uh_next >= 0 ? uh_next / p.heads : b, hd3 = uh_next >= 0 ? uh_next % p.heads : 0;
+  const int b3 = uh_next >= 0 ? user_of_slot(p, uh_next / p.heads) : b, hd3 = uh_next >= 0 ? uh_next % p.heads : 0;
   const int64_t off3 = uh_next >= 0 ? load_index(p.seq_offsets, b3, p.offsets_dtype) : 0;
   const int len3 = uh_next >= 0 ? min((int)(load_index(p.seq_offsets, b3 + 1, p.offsets_dtype) - off3), 32 * tmax) : 0;
   const MaskCtx mc = make_mask_ctx(p, b, len);

@@ -123,7 +123,7 @@ HSTU_DEV void quad_problem(const HstuAttnBwdParams& bp, int tmax, int uh, char* 
   using Q = QuadCfg<T, D>;
   static_assert(C::EB == 2, "16-bit I/O");
   const HstuAttnParams& p = bp.fwd;
-  const int b = uh / p.heads, hd = uh % p.heads;
+  const int b = user_of_slot(p, uh / p.heads), hd = uh % p.heads;
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
   const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), 32 * tmax);
   if (len <= 0) return;

@@ -385,6 +385,9 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
   return c;
 }
 
+// user of workgroup slot `slot` (HstuAttnParams::user_order: heavy-first launch order for long-tailed batches)
+HSTU_DEV int user_of_slot(const HstuAttnParams& p, int slot) { return p.user_order ? p.user_order[slot] : slot; }
+
 // 1/N, or the caller's device-side replacement for it (HstuAttnParams::attn_scale: the reference's attn_scale[0])
 HSTU_DEV float attn_scale_of(const HstuAttnParams& p) { return p.attn_scale ? *p.attn_scale : p.scale; }
 

@@ -67,8 +67,25 @@ def _idx(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return t.contiguous()
 
 
+_ORDER_CACHE = {}
+
+
+def length_order(seq_offsets: torch.Tensor) -> torch.Tensor:
+    """users by descending length (int32 permutation) -- the launch order of the reference's ``sort_by_length``
+    (ops/triton/triton_hstu_attention.py:1968-1973).  One argsort per batch: the layers of a stack call with the same
+    offsets tensor, so the last result is kept (keyed on the tensor's storage and version)."""
+    key = (seq_offsets.data_ptr(), seq_offsets._version, seq_offsets.numel(), seq_offsets.device)
+    hit = _ORDER_CACHE.get("last")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    order = torch.argsort(seq_offsets[1:] - seq_offsets[:-1], descending=True, stable=True).to(torch.int32)
+    _ORDER_CACHE["last"] = (key, order)
+    return order
+
+
 def _fill_attn_params(p: L.HstuAttnParams, q, k, v, out, seq_offsets, num_targets, max_seq_len, alpha, scale,
-                      max_attn_len, contextual_seq_len, min_full_attn_seq_len, delta_q) -> None:
+                      max_attn_len, contextual_seq_len, min_full_attn_seq_len, delta_q, user_order=None) -> None:
+    p.user_order = _vp(user_order)
     p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
     p.out = _vp(out)
     p.seq_offsets = seq_offsets.data_ptr()
@@ -94,7 +111,7 @@ def _fill_attn_params(p: L.HstuAttnParams, q, k, v, out, seq_offsets, num_target
 
 
 def attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len=0,
-             contextual_seq_len=0, min_full_attn_seq_len=0, delta_q=0) -> torch.Tensor:
+             contextual_seq_len=0, min_full_attn_seq_len=0, delta_q=0, user_order=None) -> torch.Tensor:
     for name, t in (("q", q), ("k", k), ("v", v), ("seq_offsets", seq_offsets)):
         L.require_gpu_tensor(t, name)
     if not (q.dtype == k.dtype == v.dtype):
@@ -108,7 +125,7 @@ def attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_a
         _check_attention_metadata(q, seq_offsets, max_seq_len, delta_q)
     p = L.HstuAttnParams()
     _fill_attn_params(p, q, k, v, out, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len,
-                      contextual_seq_len, min_full_attn_seq_len, delta_q)
+                      contextual_seq_len, min_full_attn_seq_len, delta_q, user_order)
     with torch.cuda.device(q.device):
         L.check(L.lib().hstu_attn_fwd(C.byref(p), L.current_stream_ptr(q.device)))
     return out
@@ -117,7 +134,7 @@ def attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_a
 def attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len=0,
              contextual_seq_len=0, min_full_attn_seq_len=0,
              dq: Optional[torch.Tensor] = None, dk: Optional[torch.Tensor] = None,
-             dv: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+             dv: Optional[torch.Tensor] = None, user_order=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """dq/dk/dv may be pre-allocated (possibly strided views of one fused buffer), as in
     hstu::hstu_mha_bwd (flash_api.cpp:111-141)."""
     for name, t in (("dout", dout), ("q", q), ("k", k), ("v", v)):
@@ -131,7 +148,7 @@ def attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale,
         return dq, dk, dv
     bp = L.HstuAttnBwdParams()
     _fill_attn_params(bp.fwd, q, k, v, None, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len,
-                      contextual_seq_len, min_full_attn_seq_len, 0)
+                      contextual_seq_len, min_full_attn_seq_len, 0, user_order)
     bp.dout, bp.dq, bp.dk, bp.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     bp.do_row_stride, bp.do_head_stride = dout.stride(0), dout.stride(1)
     bp.dq_row_stride, bp.dq_head_stride = dq.stride(0), dq.stride(1)

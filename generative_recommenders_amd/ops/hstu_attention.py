@@ -32,11 +32,12 @@ class _HstuMhaFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, max_seq_len, alpha, q, k, v, seq_offsets, num_targets, max_attn_len, contextual_seq_len,
-                min_full_attn_seq_len):
+                min_full_attn_seq_len, user_order=None):
         out = _launch.attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, alpha, 1.0 / max_seq_len,
-                               max_attn_len, contextual_seq_len, min_full_attn_seq_len)
+                               max_attn_len, contextual_seq_len, min_full_attn_seq_len, user_order=user_order)
         saved = [q, k, v, seq_offsets] + ([num_targets] if num_targets is not None else [])
         ctx.save_for_backward(*saved)
+        ctx.user_order = user_order
         ctx.has_targets = num_targets is not None
         ctx.args = (max_seq_len, alpha, max_attn_len, contextual_seq_len, min_full_attn_seq_len)
         return out
@@ -47,16 +48,19 @@ class _HstuMhaFunction(torch.autograd.Function):
         num_targets = ctx.saved_tensors[4] if ctx.has_targets else None
         max_seq_len, alpha, max_attn_len, contextual_seq_len, min_full = ctx.args
         dq, dk, dv = _launch.attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha,
-                                      1.0 / max_seq_len, max_attn_len, contextual_seq_len, min_full)
-        return None, None, dq, dk, dv, None, None, None, None, None
+                                      1.0 / max_seq_len, max_attn_len, contextual_seq_len, min_full, user_order=ctx.user_order)
+        return None, None, dq, dk, dv, None, None, None, None, None, None
 
 
 def hip_hstu_mha(max_seq_len, alpha, q, k, v, seq_offsets, num_targets=None, max_attn_len=0,
-                 contextual_seq_len=0, min_full_attn_seq_len=0) -> torch.Tensor:
+                 contextual_seq_len=0, min_full_attn_seq_len=0, sort_by_length=False) -> torch.Tensor:
     dqk, dv = q.shape[2], v.shape[2]
     qp, kp, vp = _pad_head_dim(q), _pad_head_dim(k), _pad_head_dim(v)
+    # sort_by_length: workgroups take the users in descending-length order (heavy first), as the reference's Triton
+    # launch does (triton_hstu_attention.py:1968-1973); results do not depend on it
+    order = _launch.length_order(_launch._idx(seq_offsets)) if sort_by_length and seq_offsets.numel() > 2 else None
     out = _HstuMhaFunction.apply(max_seq_len, alpha, qp, kp, vp, seq_offsets, num_targets, max_attn_len,
-                                 contextual_seq_len, min_full_attn_seq_len)
+                                 contextual_seq_len, min_full_attn_seq_len, order)
     del dqk
     return out[..., :dv] if out.shape[2] != dv else out
 
@@ -90,11 +94,10 @@ def hstu_mha(
     torch._assert(dropout_pr < 1e-6, "dropout for the HIP path not implemented")
     torch._assert(max_attn_len >= 0 and contextual_seq_len >= 0 and min_full_attn_seq_len >= 0,
                   "mask parameters must be non-negative")
-    # sort_by_length only changes the reference's launch order, never results; our grid is
-    # already ordered heavy-first per user.  enable_tma has no gfx950 meaning.
-    del training, sort_by_length, kernel, enable_tma
+    # enable_tma has no gfx950 meaning
+    del training, kernel, enable_tma
     return hip_hstu_mha(max_seq_len, alpha, q, k, v, seq_offsets, num_targets, max_attn_len,
-                        contextual_seq_len, min_full_attn_seq_len)
+                        contextual_seq_len, min_full_attn_seq_len, sort_by_length)
 
 
 def delta_hstu_mha(

@@ -147,7 +147,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, seq_offsets, num_targets, norm_eps,
                 num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
-                recompute_uvqk, recompute_normed_x):
+                recompute_uvqk, recompute_normed_x, user_order=None):
         normed_x, mean, rstd = _launch.layer_norm_fwd(x, norm_weight, norm_bias, norm_eps)
         uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
@@ -157,7 +157,8 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         k = uvqk[:, 2 * hv + ha :].view(-1, num_heads, attn_dim)
         u = _launch.silu_fwd(u_pre)
         out = _launch.attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, attn_alpha, 1.0 / max_seq_len,
-                               max_attn_len, contextual_seq_len, 0)
+                               max_attn_len, contextual_seq_len, 0, user_order=user_order)
+        ctx.user_order = user_order
         saved = [x, norm_weight, norm_bias, mean, rstd, uvqk_weight, uvqk_bias, seq_offsets]
         ctx.has_targets = num_targets is not None
         if ctx.has_targets:
@@ -195,14 +196,14 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         dq = duvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
         dk = duvqk[:, 2 * hv + ha :].view(-1, H, A)
         _launch.attn_bwd(dout.reshape(-1, H, Hd), q, k, v, seq_offsets, num_targets, N, alpha, 1.0 / N, w, c, 0,
-                         dq=dq, dk=dk, dv=dv)
+                         dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         _launch.silu_bwd(du, uvqk[:, :hv], din=duvqk[:, :hv])
         d_normed = torch.mm(duvqk, W.t())
         dW = weight_grad_mm(normed_x, duvqk)
         dbeta = duvqk.sum(dim=0)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
         return (dx, dnw.to(nw.dtype), dnb.to(nb.dtype), dW, dbeta.to(beta.dtype), None, None, None, None, None, None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def hstu_preprocess_and_attention(
@@ -243,6 +244,7 @@ def hstu_preprocess_and_attention(
             x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, seq_offsets, num_targets, norm_eps, num_heads,
             attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
             recompute_uvqk_in_backward, recompute_normed_x_in_backward,
+            _launch.length_order(_launch._idx(seq_offsets)) if sort_by_length and seq_offsets.numel() > 2 else None,
         )
         return u, attn_output, None, None
     # prefill (k, v are returned for the KV cache) or head dims that need padding

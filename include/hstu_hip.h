@@ -97,6 +97,12 @@ typedef struct HstuAttnParams {
    * sync) -- the reference's `attn_scale` tensor, of which its kernels use element 0 (flash_api.cpp:283,
    * mainloop_fwd_sm80.h:790-793, mainloop_bwd_sm80.h:892-894).  NULL: `scale` is used. */
   const float* attn_scale;
+  /* optional: a permutation of 0..batch-1 (int32, device).  Workgroup slot i then takes user user_order[i]: the
+   * reference's `sort_by_length` (ops/triton/triton_hstu_attention.py:1968-1973 sorts the lengths in descending order
+   * and walks the users in that order; the CUDA kernels' dynamic tile scheduler, flash_common.cpp:496-507, serves the
+   * same purpose): with long-tailed length distributions the heavy users start first and the launch does not end on
+   * them.  Results never depend on it.  NULL: users in index order. */
+  const int32_t* user_order;
 } HstuAttnParams;
 
 /*

@@ -407,6 +407,27 @@ def test_torch_library_operator_seam():
     assert qd.grad is not None and qd.grad.shape == qd.shape and torch.isfinite(qd.grad.float()).all()
 
 
+def test_sort_by_length_changes_the_launch_order_only():
+    """sort_by_length (ops/triton/triton_hstu_attention.py:1968-1973): heavy users first; bit-identical results,
+    forward and backward, long-tailed lengths, every backward kernel family (general d=16->32, quad d=64, fold d=128)."""
+    for d, N in ((16, 61), (64, 200), (128, 200)):
+        g = torch.Generator(device=DEV).manual_seed(d)
+        B, H = 300, 2
+        lengths = torch.randint(0, 30, (B,), generator=g, device=DEV)
+        lengths = torch.where(torch.rand(B, generator=g, device=DEV) < 0.05, torch.full_like(lengths, N), lengths)
+        off = torch.zeros(B + 1, dtype=torch.int64, device=DEV)
+        off[1:] = torch.cumsum(lengths, 0)
+        Lt = int(off[-1])
+        res = []
+        for sbl in (False, True):
+            q, k, v = (torch.randn(Lt, H, d, device=DEV, dtype=torch.bfloat16, generator=torch.Generator(device=DEV).manual_seed(i)).requires_grad_()
+                       for i in range(3))
+            out = _ops().hstu_mha(N, d**-0.5, q, k, v, off, sort_by_length=sbl)
+            out.backward(torch.ones_like(out))
+            res.append((out.detach(), q.grad, k.grad, v.grad))
+        assert all(torch.equal(a, b) for a, b in zip(*res))
+
+
 # ------------------------------------------------------------------ folded backward schedule (short sequences, d in {64, 128})
 FOLD_LENGTHS = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 200, 223, 224]
 
