@@ -33,6 +33,15 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 
+bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {
+  static const bool enabled = [] { const char* e = getenv("HSTU_SOLO"); return !(e && e[0] == '0'); }();
+  if (!enabled || p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.delta_q != 0) return false;
+  if (p.max_seq_len > 64 || p.dqk > 32 || p.dv > 32) return false;
+  if (backward && p.contextual_seq_len > 0) return false;
+  const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;          // masks ride on the S accumulator's start value (-1e30)
+  return aa == 0.f || (aa > 1e-20f && aa < 1e6f);
+}
+
 bool attn_bwd_quad_applicable(const HstuAttnBwdParams& bp) {
   static const bool enabled = [] { const char* e = getenv("HSTU_BWD_QUAD"); return !(e && e[0] == '0'); }();
   return enabled && attn_bwd_fold_applicable(bp) && bp.fwd.dqk == 64;
@@ -46,7 +55,8 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   const int a = pad_head_dim(p.dqk), v = pad_head_dim(p.dv);
   if (a == 0 || v == 0) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "head dims (%d, %d) not instantiated", p.dqk, p.dv); }
   if (p.pos_w && a != v) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "relative-bias attention is instantiated for dqk == dv"); }
-  if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
+  if (attn_solo_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_kernel<%s>", bwd ? "bwd" : "fwd", dt);
+  else if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
   else snprintf(buf, len, "hstu_attn_%s_kernel<%s,%d,%d%s>", bwd ? "bwd" : "fwd", dt, a, v, p.pos_w ? ",bias" : "");
   return HSTU_OK;

@@ -25,6 +25,12 @@ int launch_attn_bwd_bias_f32(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_bf16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_f16(const HstuAttnBwdParams& p, hipStream_t st);
 bool attn_bwd_fold_applicable(const HstuAttnBwdParams& p);
+// short sequences (max_seq_len <= 64, head dims <= 32, 16-bit I/O): one wave per (user, head) (hstu_attn_solo.cuh; HSTU_SOLO=0 disables)
+int launch_attn_fwd_solo_bf16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_fwd_solo_f16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_bwd_solo_bf16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_solo_f16(const HstuAttnBwdParams& p, hipStream_t st);
+bool attn_solo_applicable(const HstuAttnParams& p, bool backward);
 // ... and, among those, the ones the 4-wave / two-workgroups-per-CU kernel takes (head dim 64; HSTU_BWD_QUAD=0 disables)
 bool attn_bwd_quad_applicable(const HstuAttnBwdParams& p);
 // sums the per-workgroup bias-gradient rows: partial (rows, width) -> dpos_w (npos), dts_w (width - npos)
