@@ -251,61 +251,74 @@ def layer_section(args, rank, world, device):
     lengths = make_lengths("M-jag", B, N, gen, device)
     off = dp.local_offsets(lengths)
     L = int(off[-1].item())
-    torch.manual_seed(7)
-    stack = STUStack([STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=d, attention_dim=d,
-                                              output_dropout_ratio=0.0, use_group_norm=True)) for _ in range(3)])
-    stack = stack.to(device)
     x = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen).requires_grad_()
     gy = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen)
     nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
-    reducer = dp.GradientAllReducer(stack.parameters())
 
-    def step():
-        for p in stack.parameters():
-            p.grad = None
-        x.grad = None
-        y = stack(x=x, x_lengths=lengths, x_offsets=off, max_seq_len=N, num_targets=nt)
-        y.backward(gy)
-        reducer.reduce()
+    def timed(recompute):
+        """recompute=True: the reference's STULayerConfig defaults (normed x, uvqk and y recomputed in the backward --
+        a memory saving sized for 80 GB parts); False: everything kept (3 layers x 1024 users: 2.4 GB of 288)."""
+        torch.manual_seed(7)
+        stack = STUStack([STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=d, attention_dim=d,
+                                                  output_dropout_ratio=0.0, use_group_norm=True, recompute_normed_x=recompute,
+                                                  recompute_uvqk=recompute, recompute_y=recompute)) for _ in range(3)]).to(device)
+        reducer = dp.GradientAllReducer(stack.parameters())
 
-    for _ in range(3):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.layer_steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0, device)
+        def step():
+            for p in stack.parameters():
+                p.grad = None
+            x.grad = None
+            y = stack(x=x, x_lengths=lengths, x_offsets=off, max_seq_len=N, num_targets=nt)
+            y.backward(gy)
+            reducer.reduce()
+
+        for _ in range(3):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.layer_steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return dp.max_over_ranks(time.perf_counter() - t0, device), stack
+
+    elapsed_keep, _ = timed(False)
+    elapsed, stack = timed(True)
     nparams = sum(p.numel() for p in stack.parameters())
     gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
     return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,
                 user_seqs_per_s=world * B * args.layer_steps / elapsed, params=nparams,
                 allreduce_bytes=nparams * 4,
+                no_recompute=dict(ms_per_step=elapsed_keep / args.layer_steps * 1e3,
+                                  user_seqs_per_s=world * B * args.layer_steps / elapsed_keep),
                 gemm_mfma_frac_if_all_time_were_gemm=gemm_flops * args.layer_steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,
                 projections=projection_section(L, D, device))
 
 
 def projection_section(rows, D, device):
     """MFMA utilisation of the six projection GEMMs of one STU layer at the layer section's shape (hipBLASLt through
-    torch, bf16; ops/hstu_compute.py): TFLOP/s and the fraction of the dense bf16 peak, HIP events around 10 calls each."""
+    torch, bf16; the calls ops/hstu_compute.py makes: addmm with the bias, mm for the data gradients, ops/mm.py's slab-split
+    batched GEMM for the weight gradients): TFLOP/s and the fraction of the dense bf16 peak, HIP events around 10 calls each."""
+    from generative_recommenders_amd.ops.mm import weight_grad_mm
+
     dt = torch.bfloat16
     x = torch.randn(rows, D, device=device, dtype=dt)
     w_uvqk = torch.randn(D, 4 * D, device=device, dtype=dt)
+    b_uvqk = torch.randn(4 * D, device=device, dtype=dt)
     g_uvqk = torch.randn(rows, 4 * D, device=device, dtype=dt)
     y3 = torch.randn(rows, 3 * D, device=device, dtype=dt)
     w_out = torch.randn(3 * D, D, device=device, dtype=dt)
     g_out = torch.randn(rows, D, device=device, dtype=dt)
     cases = {
-        "uvqk_fwd": (lambda: torch.mm(x, w_uvqk), 2.0 * rows * D * 4 * D),
+        "uvqk_fwd": (lambda: torch.addmm(b_uvqk, x, w_uvqk), 2.0 * rows * D * 4 * D),
         "uvqk_dgrad": (lambda: torch.mm(g_uvqk, w_uvqk.t()), 2.0 * rows * D * 4 * D),
-        "uvqk_wgrad": (lambda: torch.mm(x.t(), g_uvqk), 2.0 * rows * D * 4 * D),
-        "out_fwd": (lambda: torch.mm(y3, w_out), 2.0 * rows * 3 * D * D),
+        "uvqk_wgrad": (lambda: weight_grad_mm(x, g_uvqk), 2.0 * rows * D * 4 * D),
+        "out_fwd": (lambda: torch.addmm(x, y3, w_out), 2.0 * rows * 3 * D * D),      # + the residual
         "out_dgrad": (lambda: torch.mm(g_out, w_out.t()), 2.0 * rows * 3 * D * D),
-        "out_wgrad": (lambda: torch.mm(y3.t(), g_out), 2.0 * rows * 3 * D * D),
+        "out_wgrad": (lambda: weight_grad_mm(y3, g_out), 2.0 * rows * 3 * D * D),
     }
     res = {}
     for name, (fn, flops) in cases.items():

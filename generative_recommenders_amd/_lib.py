@@ -90,6 +90,8 @@ SIGNATURES = {
     "hstu_l2_norm_fwd": (_int, [_vp, _vp, _i64, _i32, _f32, _int, _vp]),
     "hstu_l2_norm_bwd": (_int, [_vp, _vp, _vp, _i64, _i32, _f32, _int, _vp]),
     "hstu_embedding_grad_segment_sum": (_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _int, _vp]),
+    "hstu_embedding_grad_workspace_bytes": (_int, [_i64, _i32, _vp]),
+    "hstu_embedding_grad": (_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _int, _vp]),
     "hstu_jagged_write_tail": (_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _int, _vp]),
     "hstu_sampled_softmax_fwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _i32,
                                         _i32, _f32, _vp, _vp, _int, _vp]),

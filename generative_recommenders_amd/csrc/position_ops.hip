@@ -7,18 +7,13 @@
 // Forward: one workgroup per user (offset / length / query-time loads are scalar), one wave per row, 16 bytes of x
 // per lane, fp32 tables (32 bytes per lane each), fp32 math, one rounding to the I/O dtype; the two table indices of
 // every row are written out for the backward.
-// Backward (table gradients = sums of dout rows per table row): rows are sorted by table index on the host side
-// (torch.sort: plumbing), then one workgroup per chunk of 256 sorted rows walks its rows in order, keeping running
-// column sums in registers; a table row whose segment lies inside one chunk is written by exactly one workgroup
-// (plain store), segments cut by a chunk boundary add their pieces with fp32 atomics (the only non-deterministic
-// summation order, and only for those rows).
+// Backward (table gradients = sums of dout rows per table row): embedding_grad.hip.
 #include "hstu_common.cuh"
 #include "capi_internal.h"
 
 namespace hstu {
 
 constexpr int kPosThreads = 256;
-constexpr int kSegChunk = 256;
 
 // position-table row of row r of a user of length len (pt_position.py:40-73)
 HSTU_DEV int pos_index(int r, int len, int nt, int has_targets, int interleave, int max_ctx, int max_pos_ind) {
@@ -84,46 +79,6 @@ __global__ __launch_bounds__(kPosThreads) void add_ts_pos_fwd_kernel(const T* x,
   }
 }
 
-// one workgroup per chunk of kSegChunk sorted rows; thread t owns columns t, t + 256, ... (dim <= 1024)
-template <typename T>
-__global__ __launch_bounds__(kPosThreads) void segment_sum_kernel(const T* g, const int64_t* perm, const int32_t* sorted_idx,
-                                                                  int64_t n, int dim, float* table) {
-  const int64_t e0 = (int64_t)blockIdx.x * kSegChunk;
-  const int64_t e1 = min(e0 + kSegChunk, n);
-  const int t = threadIdx.x;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  int cur = sorted_idx[e0];
-  // does the first / current segment continue across a chunk boundary?  (then its piece is added atomically)
-  bool open_left = e0 > 0 && sorted_idx[e0 - 1] == cur;
-  auto flush = [&](int idx, bool shared) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = t + j * kPosThreads;
-      if (c < dim) {
-        if (shared) atomicAdd(table + (int64_t)idx * dim + c, acc[j]);
-        else table[(int64_t)idx * dim + c] = acc[j];
-      }
-      acc[j] = 0.f;
-    }
-  };
-  for (int64_t e = e0; e < e1; ++e) {
-    const int idx = sorted_idx[e];
-    if (idx != cur) {
-      flush(cur, open_left);
-      cur = idx;
-      open_left = false;
-    }
-    const T* row = g + perm[e] * dim;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = t + j * kPosThreads;
-      if (c < dim) acc[j] += (float)row[c];
-    }
-  }
-  const bool open_right = e1 < n && sorted_idx[e1] == cur;
-  flush(cur, open_left || open_right);
-}
-
 template <typename T>
 static int fwd_launch(const void* x, void* out, const void* seq_offsets, const int64_t* timestamps, const void* num_targets,
                       const float* pos_w, const float* ts_w, int32_t* pos_idx, int32_t* ts_idx, int batch, int dim,
@@ -133,15 +88,6 @@ static int fwd_launch(const void* x, void* out, const void* seq_offsets, const i
                      timestamps, num_targets, pos_w, ts_w, pos_idx, ts_idx, dim, max_ctx, max_pos_ind, max_bucket, interleave,
                      fn, alpha, is64);
   return check_launch("hstu_add_ts_pos_emb_fwd");
-}
-
-template <typename T>
-static int seg_launch(const void* g, const int64_t* perm, const int32_t* sorted_idx, int64_t n, int dim, float* table,
-                      hipStream_t st) {
-  const int blocks = (int)((n + kSegChunk - 1) / kSegChunk);
-  hipLaunchKernelGGL((segment_sum_kernel<T>), dim3(blocks), dim3(kPosThreads), 0, st, (const T*)g, perm, sorted_idx, n, dim,
-                     table);
-  return check_launch("hstu_embedding_grad_segment_sum");
 }
 
 }  // namespace hstu
@@ -176,24 +122,6 @@ int hstu_add_ts_pos_emb_fwd(const void* x, void* out, const void* seq_offsets, c
     default: return set_error(HSTU_EINVAL, "dtype must be bf16, fp16 or fp32");
   }
 #undef CALL
-}
-
-int hstu_embedding_grad_segment_sum(const void* dout, const int64_t* sorted_rows, const int32_t* sorted_idx, int64_t n,
-                                    int32_t dim, int32_t table_rows, float* table_grad, int dtype, void* stream) {
-  if (!table_grad || table_rows <= 0 || dim <= 0)
-    return set_error(HSTU_EINVAL, "hstu_embedding_grad_segment_sum: table_grad must be non-NULL, sizes positive");
-  if (dim > 4 * kPosThreads) return set_error(HSTU_EUNSUPPORTED, "hstu_embedding_grad_segment_sum: dim %d > %d", dim, 4 * kPosThreads);
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(table_grad, 0, (size_t)table_rows * dim * sizeof(float), st);
-  if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_embedding_grad_segment_sum: memset failed: %s", hipGetErrorString(e));
-  if (n == 0) return HSTU_OK;
-  if (!dout || !sorted_rows || !sorted_idx) return set_error(HSTU_EINVAL, "hstu_embedding_grad_segment_sum: NULL input");
-  switch (dtype) {
-    case HSTU_DTYPE_BF16: return seg_launch<bf16_t>(dout, sorted_rows, sorted_idx, n, dim, table_grad, st);
-    case HSTU_DTYPE_F16: return seg_launch<f16_t>(dout, sorted_rows, sorted_idx, n, dim, table_grad, st);
-    case HSTU_DTYPE_F32: return seg_launch<float>(dout, sorted_rows, sorted_idx, n, dim, table_grad, st);
-    default: return set_error(HSTU_EINVAL, "dtype must be bf16, fp16 or fp32");
-  }
 }
 
 }  // extern "C"

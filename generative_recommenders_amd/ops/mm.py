@@ -13,7 +13,9 @@ def addmm(input: torch.Tensor, mat1: torch.Tensor, mat2: torch.Tensor,
     return torch.addmm(input, mat1, mat2)
 
 
-_SPLIT_TARGET_TILES = 256          # one output tile per CU
+_SPLIT_SLABS = 16          # measured (tools/sweep_wgrad.py, profiles/r02_sweep_wgrad.json): 16 slabs are the optimum for both
+                           # projections from 194 K to 1.55 M rows (uvqk 1.04, output 0.97-1.06 PFLOP/s; 8: 0.96 / 0.72; 1: 0.48 / 0.37)
+_MIN_SLAB_ROWS = 2048
 _bmm_f32_ok = None
 
 
@@ -36,14 +38,13 @@ def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     """``x^T dy`` for x (L, K), dy (L, N): the weight gradient of ``y = x W``.  The contraction runs over ALL jagged
     rows (L ~ 10^5..10^6) while the result is one small (K, N) matrix: as a single GEMM that is K N / (128 x 256)
     output tiles -- 32 workgroups on a 256-CU part for the DLRM-v3 projections.  The rows are therefore split into
-    S slabs, multiplied as one batched GEMM (S x as many tiles) with fp32 partial results, and summed."""
+    S = 16 slabs (fewer for short inputs: a slab keeps >= 2048 rows), multiplied as one batched GEMM (S x as many tiles) with fp32 partial results, and summed."""
     L, K = x.shape
     N = dy.shape[1]
-    tiles = ((K + 127) // 128) * ((N + 255) // 256)
-    S = min(16, _SPLIT_TARGET_TILES // max(tiles, 1))
-    slab = (L // max(S, 1)) // 64 * 64
-    if not x.is_cuda or S <= 1 or slab < 2048:
+    S = min(_SPLIT_SLABS, L // _MIN_SLAB_ROWS)
+    if not x.is_cuda or S <= 1:
         return torch.mm(x.t(), dy)
+    slab = (L // S) // 64 * 64
     main = slab * S
     part = _bmm_f32(x[:main].view(S, slab, K).transpose(1, 2), dy[:main].view(S, slab, N))
     out = part.sum(dim=0)

@@ -1,7 +1,7 @@
 """Drop-in for generative_recommenders/ops/position.py:38-96: ``add_timestamp_positional_embeddings`` -- the step
 right before the STU stack: ``alpha * seq_embeddings + position_table[pos index] + timestamp_table[time bucket]``
 over jagged rows.  One HIP kernel forward (indices + gather + add), table gradients by a sorted segment sum
-(csrc/position_ops.hip); semantics of ops/pytorch/pt_position.py:40-134."""
+(csrc/position_ops.hip, csrc/embedding_grad.hip); semantics of ops/pytorch/pt_position.py:40-134."""
 
 import ctypes as C
 import os
@@ -33,14 +33,15 @@ def _max_time_bucket(ts_w: torch.Tensor) -> int:
 
 
 def _table_grad(g: torch.Tensor, idx: torch.Tensor, table_rows: int) -> torch.Tensor:
-    """sum of the rows of g per table index -> (table_rows, D) fp32"""
-    dim = g.shape[1]
+    """sum of the rows of g per table index -> (table_rows, D) fp32 (grouping and segment sum: csrc/embedding_grad.hip)"""
+    n, dim = g.shape
     out = torch.empty((table_rows, dim), dtype=torch.float32, device=g.device)
-    sorted_idx, perm = torch.sort(idx, stable=True)        # plumbing: the kernel walks rows grouped by table row
+    need = C.c_int64(0)
+    L.check(L.lib().hstu_embedding_grad_workspace_bytes(n, table_rows, C.byref(need)))
+    ws = torch.empty(max(need.value, 256), dtype=torch.uint8, device=g.device)
     with torch.cuda.device(g.device):
-        L.check(L.lib().hstu_embedding_grad_segment_sum(g.data_ptr(), perm.data_ptr(), sorted_idx.data_ptr(), g.shape[0],
-                                                        dim, table_rows, out.data_ptr(), L.torch_dtype_code(g.dtype),
-                                                        L.current_stream_ptr(g.device)))
+        L.check(L.lib().hstu_embedding_grad(g.data_ptr(), idx.data_ptr(), n, dim, table_rows, out.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), L.torch_dtype_code(g.dtype), L.current_stream_ptr(g.device)))
     return out
 
 

@@ -259,9 +259,17 @@ int hstu_add_ts_pos_emb_fwd(const void* x, void* out, const void* seq_offsets, c
                             int32_t* ts_idx, int32_t batch, int32_t dim, int32_t max_contextual_seq_len,
                             int32_t max_pos_ind, int32_t max_time_bucket, int32_t interleave_targets,
                             int32_t time_bucket_fn, float alpha, int dtype, int index_dtype, void* stream);
-/* table_grad[i, :] = sum over e with sorted_idx[e] == i of dout[sorted_rows[e], :]  (fp32, (table_rows, dim), zeroed
- * here): the index_select backward of one embedding table, rows pre-sorted by table index.  dim <= 1024.  Replaces
- * _add_embeddings_bwd_kernel (ops/triton/triton_position.py:188-238, host side :339-407). */
+/* table_grad[i, :] = sum over the rows e with idx[e] == i of dout[e, :]  (fp32, (table_rows, dim), zeroed here): the
+ * index_select backward of one embedding table.  Rows are grouped by table index inside (a radix sort over the
+ * ceil(log2(table_rows)) significant bits, stable: each table row's sum runs in row order), then summed by
+ * segment.  `workspace`: device memory, 256-byte aligned, at least hstu_embedding_grad_workspace_bytes(n, table_rows)
+ * bytes.  Rows of dout: 16-byte multiples, <= 4 KiB.  0 <= idx[e] < table_rows (not checked).  Replaces
+ * _add_embeddings_bwd_kernel and the sort on its host side (ops/triton/triton_position.py:188-238, :339-407). */
+int hstu_embedding_grad_workspace_bytes(int64_t n, int32_t table_rows, int64_t* bytes);
+int hstu_embedding_grad(const void* dout, const int32_t* idx, int64_t n, int32_t dim, int32_t table_rows, float* table_grad,
+                        void* workspace, int64_t workspace_bytes, int dtype, void* stream);
+/* The second half alone, for callers that hold the rows sorted already: table_grad[i, :] = sum over e with
+ * sorted_idx[e] == i of dout[sorted_rows[e], :]. */
 int hstu_embedding_grad_segment_sum(const void* dout, const int64_t* sorted_rows, const int32_t* sorted_idx, int64_t n,
                                     int32_t dim, int32_t table_rows, float* table_grad, int dtype, void* stream);
 

@@ -103,3 +103,31 @@ def test_positional_encoder_module_names_and_cpu_error():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(max_seq_len=4, seq_lengths=torch.tensor([2]), seq_offsets=torch.tensor([0, 2]), seq_timestamps=torch.tensor([1, 2]),
           seq_embeddings=torch.zeros(2, 16), num_targets=None)
+
+
+@pytest.mark.parametrize("dtype,dim,rows,n", [(torch.bfloat16, 512, 8192, 100_003), (torch.float32, 64, 37, 5_000), (torch.float16, 1024, 2049, 20_001),
+                                              (torch.float32, 1024, 3, 777), (torch.bfloat16, 8, 1, 300), (torch.bfloat16, 512, 100, 0)])
+def test_table_gradient_grouping_and_segment_sum(dtype, dim, rows, n):
+    """csrc/embedding_grad.hip on its own: table row counts that are no power of two, one-row tables, segments cut by
+    several 64-row runs and segments of one row, n = 0, 16-byte .. 4-KiB rows; the values are small integers, so every
+    fp32 sum is exact whatever the order and the comparison is bit for bit.  The stable grouping makes a second call
+    return the same bits for real-valued input too."""
+    pos = _op()
+    g = torch.Generator(device=DEV).manual_seed(n + rows)
+    idx = torch.randint(0, rows, (n,), generator=g, device=DEV, dtype=torch.int32)
+    if n > 1000:
+        idx[100:700] = rows - 1                     # one long segment across run boundaries
+    dout = torch.randint(-8, 9, (n, dim), generator=g, device=DEV).to(dtype)
+    got = pos._table_grad(dout, idx, rows)
+    ref = torch.zeros(rows, dim, dtype=torch.float32, device=DEV).index_add_(0, idx.long(), dout.float())
+    assert torch.equal(got, ref)
+    if n:
+        real = torch.randn(n, dim, generator=g, device=DEV).to(dtype)
+        a, b = pos._table_grad(real, idx, rows), pos._table_grad(real, idx, rows)
+        ref = torch.zeros(rows, dim, dtype=torch.float64, device=DEV).index_add_(0, idx.long(), real.double())
+        torch.testing.assert_close(a.double(), ref, rtol=1e-5, atol=1e-4)
+        cut = torch.zeros(rows, dtype=torch.bool, device=DEV)      # rows whose segment no run boundary cuts are order-exact
+        sidx = torch.sort(idx.long(), stable=True).values
+        cut[sidx[63::64]] = True
+        cut[sidx[64::64]] = True
+        assert torch.equal(a[~cut], b[~cut])
