@@ -71,9 +71,14 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   const int hist = attn_bwd_bias_lds(p, &ts_copies);
   const int nw = bwd_tiles_inst<T, DQK, DV>(p.max_seq_len, hist);
   const int nkb = (p.max_seq_len + 32 * nw - 1) / (32 * nw);
-  const int groups = (p.batch * p.heads + 7) / 8;
+  // research-path bias with the whole sequence in one key block: one workgroup per USER walks the heads and keeps the
+  // time-bucket matrix as bytes in LDS (1 KiB per tile pair of the causal triangle), see hstu_attn_bwd.cuh
+  const int cache_bytes = nw * (nw + 1) / 2 * 1024;
+  const bool head_loop = BIAS && nkb == 1 && p.heads > 1 && p.ts_w && p.timestamps && p.num_buckets <= 255 && p.contextual_seq_len == 0 &&
+                         C::smem_bytes(nw, hist + cache_bytes) <= kLdsBudget && attn_bias_head_loop_enabled();
+  const int groups = ((head_loop ? p.batch : p.batch * p.heads) + 7) / 8;
   const int nblocks = groups * 8 * nkb;
-  const int smem = C::smem_bytes(nw, hist + (nkb > 1 ? kDqScratchBytes : 0));
+  const int smem = C::smem_bytes(nw, hist + (nkb > 1 ? kDqScratchBytes : 0) + (head_loop ? cache_bytes : 0));
   if (smem > kLdsBudget) return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd: max_seq_len %d needs %d bytes of LDS for the bias histograms", p.max_seq_len, smem);
   auto kern = hstu_attn_bwd_kernel<T, DQK, DV, BIAS>;
   if (smem > 64 * 1024) {
@@ -96,7 +101,7 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
     hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblocks * hw * sizeof(float), st);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial, ts_copies);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial, ts_copies, head_loop ? hist : 0);
   if (int e = check_launch("hstu_attn_bwd")) return e;
   if (nkb > 1) {
     const int64_t n = bp.total_rows * p.heads * (int64_t)(p.dqk / (16 / Elem<T>::kBytes));   // 16 bytes of dq per thread

@@ -66,6 +66,15 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
 // add to the SAME histogram entry and the LDS atomics serialise.  Every lane group therefore gets its own copy of
 // the time-bucket histogram (entry b of copy c at b * copies + c: the lanes of a wave that share a bucket hit
 // consecutive words), as many copies as fit without costing a key tile; the copies are summed at the flush.
+// HSTU_BIAS_HEAD_LOOP=0: one workgroup per (user, head) for the research-path backward, as before (A/B measurements)
+bool attn_bias_head_loop_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("HSTU_BIAS_HEAD_LOOP");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies) {
   if (ts_copies) *ts_copies = 1;
   if (!p.pos_w) return 0;

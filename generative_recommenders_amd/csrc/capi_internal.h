@@ -42,6 +42,7 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
 int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int extra_lds);
 // LDS bytes of the research-path bias state of a backward workgroup (histograms with *ts_copies privatised copies of
 // the time-bucket histogram + the staged tables) and the number of copies chosen; 0 without bias
+bool attn_bias_head_loop_enabled();
 int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies);
 
 inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }

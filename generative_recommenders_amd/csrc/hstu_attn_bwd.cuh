@@ -27,7 +27,12 @@
 // q, k, v and dout are each read from HBM exactly once per (user, head) in the
 // single-block case; dq, dk, dv are written once.
 #pragma once
+#include <type_traits>
 #include "hstu_attn_fwd.cuh"
+
+#ifndef BIAS_ABLATE
+#define BIAS_ABLATE 0   // timing experiments only (wrong results): 1 no position histogram, 2 no time histogram, 4 bias value 0
+#endif
 
 namespace hstu {
 
@@ -197,7 +202,8 @@ HSTU_DEV void bwd_dq_tile(const HstuAttnBwdParams& bp, const MaskCtx& mc, const 
 
 template <typename T, int DQK, int DV, bool BIAS = false>
 __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAttnBwdParams bp, int nkb, int nw,
-                                                                    float* dq_accum, float* bias_partial, int ts_copies) {
+                                                                    float* dq_accum, float* bias_partial, int ts_copies,
+                                                                    int bucket_cache_off) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -214,8 +220,14 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int grp = bid / (8 * nkb), rem = bid % (8 * nkb);
   const int kb = rem / 8;
   const int uh = grp * 8 + (rem & 7);
-  if (uh >= p.batch * p.heads) return;
-  const int b = user_of_slot(p, uh / p.heads), hd = uh % p.heads;
+  // bucket_cache_off > 0 (research-path bias, one key block): ONE workgroup walks all heads of a user.  The time-bucket
+  // matrix depends on the user only: the first head computes it (hardware log2 + the exactness check, ~12 VALU
+  // instructions and a timestamp read per element) and leaves it as one byte per element in LDS, the other heads read
+  // 8 bytes per lane and half tile; the tables are staged, the histograms flushed and reduced once per user.
+  const bool head_loop = BIAS && bucket_cache_off > 0;
+  if (uh >= (head_loop ? p.batch : p.batch * p.heads)) return;
+  const int b = user_of_slot(p, head_loop ? uh : uh / p.heads), hd_first = head_loop ? 0 : uh % p.heads;
+  const int n_heads = head_loop ? p.heads : 1;
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
   const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
   const int kb0 = kb * 32 * nw;
@@ -248,6 +260,35 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
     for (int i = tid; i < hist_floats; i += kBwdThreads) hpos[i] = 0.f;
   }
 
+  char* const bcache = (char*)hpos + bucket_cache_off;
+  const float scale_v = attn_scale_of(p);
+  const float ds_scale = scale_v * p.alpha;
+  const int key = k0w + n32;
+  const bool key_ok = tile_owner && key < len;
+  int t_k32 = 0;
+  // Time-bucket histogram: a lane owns ONE key for the whole kernel and walks its query rows in order, so the time
+  // difference -- and with it the (logarithmic) bucket -- changes only a handful of times per tile.  The running sum of
+  // the current bucket stays in a register and goes to the LDS histogram when the bucket changes (LDS float atomics
+  // cost ~200 cycles per wave instruction here; one per element was half of this kernel's time).
+  int ts_cur = 0;
+  float ts_sum = 0.f;
+  auto ts_cache_add = [&](int bkt_, float v_) {
+    if (bkt_ != ts_cur) {
+      if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
+      ts_cur = bkt_;
+      ts_sum = 0.f;
+    }
+    ts_sum += v_;
+  };
+
+  const int tid_wg = tid;
+  for (int hi = 0; hi < n_heads; ++hi) {
+  const int hd = hd_first + hi;
+  // (the thread id is laundered per head: the per-thread offsets of the prologue and the epilogue are recomputed there
+  // instead of being hoisted out of the head loop and kept alive across the query-tile loop -- 70 registers)
+  int tid_h = tid_wg;
+  if constexpr (BIAS) asm volatile("" : "+v"(tid_h));
+  const int tid = tid_h, lane = tid_h & 63, n32 = lane & 31, hf = lane >> 5;
   const char* qbase = (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
   const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
   const char* vbase = (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * C::EB;
@@ -290,33 +331,13 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   __syncthreads();
   HSTU_MARK(3);
 
-  const float scale_v = attn_scale_of(p);
-  const float ds_scale = scale_v * p.alpha;
-  const int key = k0w + n32;
-  const bool key_ok = tile_owner && key < len;
-  const int key_id = mc.id_of(key);
-  int64_t t_k = 0;
-  int t_k32 = 0;
   if constexpr (BIAS) {   // (after the barrier above: the staged tables are visible)
-    bc.finish(kBwdWaves);
-    t_k = bc.ts_at(key);
-    if (bc.small) t_k32 = bc.t32_at(key);
-  }
-
-  // Time-bucket histogram: a lane owns ONE key for the whole kernel and walks its query rows in order, so the time
-  // difference -- and with it the (logarithmic) bucket -- changes only a handful of times per tile.  The running sum of
-  // the current bucket stays in a register and goes to the LDS histogram when the bucket changes (LDS float atomics
-  // cost ~200 cycles per wave instruction here; one per element was half of this kernel's time).
-  int ts_cur = 0;
-  float ts_sum = 0.f;
-  auto ts_cache_add = [&](int bkt_, float v_) {
-    if (bkt_ != ts_cur) {
-      if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
-      ts_cur = bkt_;
-      ts_sum = 0.f;
+    if (hi == 0) {
+      bc.finish(kBwdWaves);
+      if (bc.small) t_k32 = bc.t32_at(key);
     }
-    ts_sum += v_;
-  };
+  }
+  const bool bkt_cached = head_loop && hi > 0;
 
   for (int it = it_hi - 1; it >= it_lo; --it) {
     const int i0 = it << 5;
@@ -367,8 +388,10 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
         int pidx[8], bkt[8];
         float xb[8];
         int tq4[8];
+        // this lane's 8 bucket bytes of the half tile (pairs of one key block: it >= wave)
+        const int bslot_off = ((((it * (it + 1)) >> 1) + wave) * 2 + h8) * 512;    // (scalar; the lane part is added at the use)
         if constexpr (BIAS) {
-          if (bc.small) {   // next-item timestamps of the 4 consecutive query rows of a register group: one 16-byte LDS read
+          if (bc.small && !bkt_cached) {   // next-item timestamps of the 4 consecutive query rows of a register group: one 16-byte LDS read
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
               const auto t4 = bc.t32x4_next(i0 + 8 * (2 * h8 + g) + 4 * hf);
@@ -380,14 +403,26 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
 #pragma unroll
         for (int j = 0; j < 8; ++j) xb[j] = 0.f;
         if constexpr (BIAS) {
-          if (bc.small) {   // (workgroup-uniform: one branch per half tile, not one per element)
+          if (bkt_cached) {
+            const u32x2 w = *LDS_PTR(const u32x2, bcache + bslot_off + 8 * lane_p);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bkt[j] = bc.bucket32(tq4[j], t_k32);
+            for (int j = 0; j < 8; ++j) bkt[j] = (int)((w[j >> 2] >> (8 * (j & 3))) & 255u);
           } else {
+            if (bc.small) {   // (workgroup-uniform: one branch per half tile, not one per element)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int r = 8 * h8 + j;
-              bkt[j] = bc.bucket(bc.ts_at(i0 + (r & 3) + 8 * (r >> 2) + 4 * hf + 1), t_k);
+              for (int j = 0; j < 8; ++j) bkt[j] = bc.bucket32(tq4[j], t_k32);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int r = 8 * h8 + j;
+                bkt[j] = bc.bucket(bc.ts_at(i0 + (r & 3) + 8 * (r >> 2) + 4 * hf + 1), bc.ts_at(key));
+              }
+            }
+            if (head_loop) {
+              u32x2 w = {0u, 0u};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) w[j >> 2] |= (unsigned)bkt[j] << (8 * (j & 3));
+              *LDS_PTR(u32x2, bcache + bslot_off + 8 * lane_p) = w;
             }
           }
 #pragma unroll
@@ -395,7 +430,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
             const int r = 8 * h8 + j;
             const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             pidx[j] = bc.pos_index(qi, key);
-            xb[j] = bc.value(pidx[j], bkt[j]);
+            xb[j] = (BIAS_ABLATE & 4) ? 0.f : bc.value(pidx[j], bkt[j]);
           }
         }
         {   // two elements per VALU instruction where the ISA has a packed fp32 form (mul / add / fma)
@@ -427,7 +462,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           for (int j = 0; j < 8; ++j) {
             const int r = 8 * h8 + j;
             const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const bool ok = key_ok & (qi < len) & mc.valid_ids(qi, key, mc.id_of(qi), key_id);
+            const bool ok = key_ok & (qi < len) & mc.valid_ids(qi, key, mc.id_of(qi), mc.id_of(key));
             pv[j] = ok ? pv[j] : 0.f;
             dsv[j] = ok ? dsv[j] : 0.f;
           }
@@ -447,12 +482,14 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
             for (int j = 2; j >= 0; --j)
               t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x101, 0xf, 0xf, true)) +
                   dsv[4 * gg + j];
-            if (t != 0.f) atomicAdd(hpos + pidx[4 * gg], t);
+            if (!(BIAS_ABLATE & 1) && t != 0.f) atomicAdd(hpos + pidx[4 * gg], t);
 #pragma unroll
             for (int j = 1; j < 4; ++j)
-              if (p16 < j && dsv[4 * gg + j] != 0.f) atomicAdd(hpos + pidx[4 * gg + j], dsv[4 * gg + j]);
+              if (!(BIAS_ABLATE & 1) && p16 < j && dsv[4 * gg + j] != 0.f) atomicAdd(hpos + pidx[4 * gg + j], dsv[4 * gg + j]);
+            // (collecting the pushed-out elements on lanes 0..2 with four more row shifts -- one atomic instead of three --
+            // was measured: -1.4 %, and one spilled register at head dim 128)
           }
-          if (bc.lts) {
+          if (!(BIAS_ABLATE & 2) && bc.lts) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ts_cache_add(bkt[j], dsv[j]);
           }
@@ -529,23 +566,6 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
     bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_prev, nw, kb0, it_lo << 5, wave, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
   }
   HSTU_MARK(21);
-  if constexpr (BIAS) {
-    if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
-    __syncthreads();
-    float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
-    const int npos = 2 * p.max_seq_len - 1;
-    for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) {
-      float v;
-      if (i < npos) {
-        v = hpos[i];
-      } else {
-        v = 0.f;
-        const float* cp = hts + (i - npos) * ts_copies;
-        for (int c = 0; c < ts_copies; ++c) v += cp[c];
-      }
-      row[i] = v * scale_v;
-    }
-  }
   // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv.  16-bit I/O with the
   // instantiated head dims: through LDS -- each owner wave writes its two [32 keys][D] tiles over its own (dead) K/V
   // tiles in the swizzled row-major layout, reads 16-byte units back with 16 consecutive lanes per row and stores
@@ -591,7 +611,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           if (row < rows_valid) gstore16(dvt + (int64_t)row * bp.dv_row_stride * C::EB + unit * 16, v);
         }
       }
-      return;
+      if (hi + 1 < n_heads) __syncthreads();   // copy-out reads done before the next head's K/V land
+      continue;
     }
   }
   if (key_ok) {
@@ -616,6 +637,25 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
                       dv_acc[d][4 * rq + 3] * scale_v);
         }
     }
+  if (hi + 1 < n_heads) __syncthreads();
+  }   // heads
+  if constexpr (BIAS) {
+    if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
+    __syncthreads();
+    float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
+    const int npos = 2 * p.max_seq_len - 1;
+    for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) {
+      float v;
+      if (i < npos) {
+        v = hpos[i];
+      } else {
+        v = 0.f;
+        const float* cp = hts + (i - npos) * ts_copies;
+        for (int c = 0; c < ts_copies; ++c) v += cp[c];
+      }
+      row[i] = v * scale_v;
+    }
+  }
 }
 
 // fp32 dq accumulator (rows, H, dqk) -> dq in the I/O dtype (strided).  One thread per 16 bytes of OUTPUT: 8 features
