@@ -1,7 +1,7 @@
 // Per-dtype launchers: pick the (padded) head-dim instantiation and launch.
 #pragma once
 #include "capi_internal.h"
-#include "hstu_attn_bwd.cuh"
+#include "hstu_attn_bwd_fold.cuh"
 
 namespace hstu {
 
@@ -63,10 +63,36 @@ static int bwd_tiles_inst(int max_seq_len, int extra_lds) {
   return nw < 1 ? 1 : nw;
 }
 
+// research-path bias on the folded schedule (hstu_attn_bwd_fold_bias_kernel): head dim 64, 16-bit I/O
+template <typename T, int D>
+static int launch_bwd_fold_bias_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
+  using F = FoldCfg<T, D, D>;
+  const HstuAttnParams& p = bp.fwd;
+  const int tmax = (p.max_seq_len + 31) / 32;
+  int ts_copies = 1, hist = 0, smem = 0;
+  if (!attn_bwd_fold_bias_lds(p, F::smem_bytes(), &ts_copies, &hist, &smem)) return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd(fold, bias): LDS");
+  const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
+  auto kern = hstu_attn_bwd_fold_bias_kernel<T, D>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int grid = p.batch < n_cu ? p.batch : n_cu;
+  const int hw = 2 * p.max_seq_len + p.num_buckets;
+  float* partial = (float*)bp.workspace;
+  e = hipMemsetAsync(partial, 0, (size_t)grid * hw * sizeof(float), st);
+  if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), smem, st, bp, tmax, partial, ts_copies, hist, tables);
+  if (int rc = check_launch("hstu_attn_bwd(fold, bias)")) return rc;
+  return launch_bias_grad_reduce(partial, grid, hw, 2 * p.max_seq_len - 1, bp.dpos_w, bp.dts_w, st);
+}
+
 template <typename T, int DQK, int DV, bool BIAS>
 static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   using C = BwdCfg<T, DQK, DV>;
   const HstuAttnParams& p = bp.fwd;
+  if constexpr (BIAS && sizeof(T) == 2 && DQK == 64 && DV == 64) {
+    if (attn_bwd_fold_bias_applicable(bp)) return launch_bwd_fold_bias_inst<T, 64>(bp, st);
+  }
   int ts_copies = 1;
   const int hist = attn_bwd_bias_lds(p, &ts_copies);
   const int nw = bwd_tiles_inst<T, DQK, DV>(p.max_seq_len, hist);

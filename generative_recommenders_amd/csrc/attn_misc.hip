@@ -58,6 +58,7 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   if (attn_solo_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_kernel<%s>", bwd ? "bwd" : "fwd", dt);
   else if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
+  else if (bwd && attn_bwd_fold_bias_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_bias_kernel<%s,64>", dt);
   else snprintf(buf, len, "hstu_attn_%s_kernel<%s,%d,%d%s>", bwd ? "bwd" : "fwd", dt, a, v, p.pos_w ? ",bias" : "");
   return HSTU_OK;
 }
@@ -66,6 +67,35 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
 // add to the SAME histogram entry and the LDS atomics serialise.  Every lane group therefore gets its own copy of
 // the time-bucket histogram (entry b of copy c at b * copies + c: the lanes of a wave that share a bucket hit
 // consecutive words), as many copies as fit without costing a key tile; the copies are summed at the flush.
+// LDS of the folded research-path backward behind the folded kernel's own `base` bytes: histograms (as many time-bucket
+// copies as fit: 32, 8 or 1), tables, one bucket byte per element of the causal triangle of 7 tiles
+bool attn_bwd_fold_bias_lds(const HstuAttnParams& p, int base, int* ts_copies, int* hist_bytes, int* smem) {
+  const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets), cache = 28 * 1024;
+  for (int c : {32, 8, 1}) {
+    const int hist = ((2 * p.max_seq_len + (p.num_buckets + 1) * c) * 4 + 15) / 16 * 16;
+    if (base + hist + tables + cache <= kLdsBudget) {
+      if (ts_copies) *ts_copies = c;
+      if (hist_bytes) *hist_bytes = hist;
+      if (smem) *smem = base + hist + tables + cache;
+      return true;
+    }
+  }
+  return false;
+}
+
+// research-path backward on the folded schedule: head dim 64, 16-bit I/O, the whole sequence in 7 tiles, position AND
+// time tables (HSTU_BIAS_FOLD=0: the general kernel, A/B measurements)
+bool attn_bwd_fold_bias_applicable(const HstuAttnBwdParams& bp) {
+  const HstuAttnParams& p = bp.fwd;
+  static const bool enabled = [] { const char* e = getenv("HSTU_BIAS_FOLD"); return !(e && e[0] == '0'); }();
+  if (!enabled || !p.pos_w || !p.ts_w || !p.timestamps) return false;
+  if (p.dtype == HSTU_DTYPE_F32 || p.contextual_seq_len > 0 || p.dqk != 64 || p.dv != 64) return false;
+  if (p.num_buckets > 255 || (p.max_seq_len + 31) / 32 > 7) return false;
+  const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;
+  if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
+  return attn_bwd_fold_bias_lds(p, (7 + 2) * 2 * 32 * 64 * 2 + 8 * 32 * 64, nullptr, nullptr, nullptr);
+}
+
 // HSTU_BIAS_HEAD_LOOP=0: one workgroup per (user, head) for the research-path backward, as before (A/B measurements)
 bool attn_bias_head_loop_enabled() {
   static const bool on = [] {

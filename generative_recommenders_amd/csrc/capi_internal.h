@@ -43,6 +43,8 @@ int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int ex
 // LDS bytes of the research-path bias state of a backward workgroup (histograms with *ts_copies privatised copies of
 // the time-bucket histogram + the staged tables) and the number of copies chosen; 0 without bias
 bool attn_bias_head_loop_enabled();
+bool attn_bwd_fold_bias_lds(const HstuAttnParams& p, int base, int* ts_copies, int* hist_bytes, int* smem);
+bool attn_bwd_fold_bias_applicable(const HstuAttnBwdParams& bp);
 int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies);
 
 inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }
@@ -50,7 +52,8 @@ constexpr int kLdsBudget = 160 * 1024;
 // bytes of the bias tables a workgroup stages in LDS: pos_w (2N-1 floats), ts_w (nb+1 floats), N int64 timestamps,
 // their int32 offsets
 inline int bias_table_bytes(int max_seq_len, int num_buckets) {
-  return ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16 + (max_seq_len * 8 + 15) / 16) * 16 +
+  return 128 /* zeros in front of the position table: see stage_bias_tables */ +
+         ((2 * max_seq_len * 4 + 15) / 16 + ((num_buckets + 1) * 4 + 15) / 16 + (max_seq_len * 8 + 15) / 16) * 16 +
          (2 * ((max_seq_len + 32 + 3) / 4 * 4) * 4 + 8 * 4 + 15) / 16 * 16;   // + int32 offsets and their copy shifted by one (padded), one range flag per wave
 }
 constexpr int kDqScratchBytes = 8 * 4096;   // general backward, several key blocks: one [32 q][32 d] fp32 tile per wave

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n32 = lane & 31, hf = lane >> 5;
+  const int n32 = lane & 31;
 
   // ---- work decode (same grouping as forward: key blocks of one (user, head) adjacent)
   const int bid = blockIdx.x;
@@ -266,20 +266,8 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int key = k0w + n32;
   const bool key_ok = tile_owner && key < len;
   int t_k32 = 0;
-  // Time-bucket histogram: a lane owns ONE key for the whole kernel and walks its query rows in order, so the time
-  // difference -- and with it the (logarithmic) bucket -- changes only a handful of times per tile.  The running sum of
-  // the current bucket stays in a register and goes to the LDS histogram when the bucket changes (LDS float atomics
-  // cost ~200 cycles per wave instruction here; one per element was half of this kernel's time).
-  int ts_cur = 0;
-  float ts_sum = 0.f;
-  auto ts_cache_add = [&](int bkt_, float v_) {
-    if (bkt_ != ts_cur) {
-      if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
-      ts_cur = bkt_;
-      ts_sum = 0.f;
-    }
-    ts_sum += v_;
-  };
+  TsRun ts_run;   // running sum of the current time bucket (hstu_common.cuh)
+  ts_run.init(hts, ts_copies, my_copy);
 
   const int tid_wg = tid;
   for (int hi = 0; hi < n_heads; ++hi) {
@@ -491,7 +479,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
           }
           if (!(BIAS_ABLATE & 2) && bc.lts) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ts_cache_add(bkt[j], dsv[j]);
+            for (int j = 0; j < 8; ++j) ts_run.add(bkt[j], dsv[j]);
           }
         }
         pb[h8] = E::pack8(pv);
@@ -640,7 +628,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   if (hi + 1 < n_heads) __syncthreads();
   }   // heads
   if constexpr (BIAS) {
-    if (ts_sum != 0.f) atomicAdd(hts + ts_cur * ts_copies + my_copy, ts_sum);
+    ts_run.flush();
     __syncthreads();
     float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
     const int npos = 2 * p.max_seq_len - 1;

@@ -88,11 +88,26 @@ HSTU_DEV void fold_tile_dma(char* tile, const char* base, int64_t row_stride_byt
 // dQ GEMM (a 32-lane group reads rows 8g..8g+3 of g = 0,1: four 64-byte quarters x two different 32-byte halves).
 HSTU_DEV int fold_ds_off(int row, int chunk) { return (row << 6) + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
+// Research-path bias inside the folded schedule (hstu_attn_bwd_fold_bias_kernel): the per-workgroup state the pairs need.
+// FoldNoBias compiles every use away.
+struct FoldNoBias {
+  static constexpr bool on = false;
+};
+struct FoldBias {
+  static constexpr bool on = true;
+  BiasCtx bc;          // staged tables + this user's timestamps (LDS)
+  float* hpos;         // LDS histograms of dS': position bins, then time buckets x ts_copies
+  float* hts;
+  char* bcache;        // one byte per element of the causal triangle: the time bucket (user-invariant across heads)
+  bool cached;         // the bucket bytes of this user are in place (heads after the first)
+  TsRun ts_run;        // running sum of the current time bucket (hstu_common.cuh)
+};
+
 // One (query tile i0, key tile k0) pair on the owner wave: S, dP, P', dS', dV += , dK +=, publish dS'.
-template <typename T, int DQK, int DV>
-HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* __restrict__ Kw, const char* __restrict__ Vw,
+template <typename T, int DQK, int DV, typename BX = FoldNoBias>
+HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char* __restrict__ Kw, const char* __restrict__ Vw,
                         const char* __restrict__ Qs, const char* __restrict__ dOs, char* __restrict__ myds, int i0, int k0, f32x16 (&dk_acc)[DQK / 32],
-                        f32x16 (&dv_acc)[DV / 32], int lane, int dmvm HSTU_TRACE_ARG) {
+                        f32x16 (&dv_acc)[DV / 32], int lane, int dmvm, BX& bx HSTU_TRACE_ARG) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -165,17 +180,70 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
     }
   }
   HSTU_MARK(11);
+  int t_k32 = 0;
+  if constexpr (BX::on) {
+    if (bx.bc.small) t_k32 = bx.bc.t32_at(key);
+  }
+  // (bias: dS' in fp32, the buckets and the first position bin of both halves stay live for the histograms, which run
+  // AFTER the dV / dK stream: LDS operations complete in order, and a ds_add in front of the stream's fragment reads
+  // delays every one of them by the atomic's latency)
+  float ds_keep[BX::on ? 16 : 1];
+  int bkt_keep[BX::on ? 16 : 1];
+  int pbase_keep[2] = {0, 0};
   auto elem = [&](const int h8) {
     float pv[8], dsv[8];
+    float xb[8];
+    int bkt[8];
+    int pbase = 0;       // position bin of the half's first element; row j + 8 gg of the half: pbase - j - 8 gg
+    if constexpr (BX::on) {
+      // bias term of the 8 elements of this half (hstu_attn_bwd.cuh, BIAS): time buckets from the user's byte matrix
+      // (heads after the first) or computed and left there (first head)
+      const BiasCtx& bc = bx.bc;
+      const int qt = i0 >> 5, kt = k0 >> 5;
+      char* const bslot = bx.bcache + ((((qt * (qt + 1)) >> 1) + kt) * 2 + h8) * 512 + 8 * lane;
+      if (bx.cached) {
+        const u32x2 w = *LDS_PTR(const u32x2, bslot);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bkt[j] = (int)((w[j >> 2] >> (8 * (j & 3))) & 255u);
+      } else {
+        if (bc.small) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const auto t4 = bc.t32x4_next(i0 + 8 * (2 * h8 + g) + 4 * hf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bkt[4 * g + j] = bc.bucket32(t4[j], t_k32);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * h8 + j;
+            bkt[j] = bc.bucket(bc.ts_at(i0 + (r & 3) + 8 * (r >> 2) + 4 * hf + 1), bc.ts_at(key));
+          }
+        }
+        u32x2 w = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j >> 2] |= (unsigned)bkt[j] << (8 * (j & 3));
+        *LDS_PTR(u32x2, bslot) = w;
+      }
+      pbase = bc.pos_index(i0 + 16 * h8 + 4 * hf, key);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] = (BIAS_ABLATE & 4) ? 0.f : bc.value(pbase - (j & 3) - 8 * (j >> 2), bkt[j]);
+    }
     {   // two elements per VALU instruction where the ISA has a packed fp32 form (mul / add / fma): -1.6 % kernel time
       const f32x2 a2 = {p.alpha, p.alpha};
       const f32x2 c2 = {-1.44269504088896340736f * p.alpha, -1.44269504088896340736f * p.alpha};
+      const f32x2 nl2 = {-1.44269504088896340736f, -1.44269504088896340736f};
       const f32x2 one2 = {1.f, 1.f};
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
         const int r = 8 * h8 + j;
         const f32x2 sv = {s[r], s[r + 1]}, dpv = {dp[r], dp[r + 1]};
-        const f32x2 x = sv * a2, t = sv * c2;
+        f32x2 x = sv * a2, t = sv * c2;
+        if constexpr (BX::on) {
+          const f32x2 bv = {xb[j], xb[j + 1]};
+          x = x + bv;
+          t = x * nl2;
+        }
         const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
         const f32x2 dn = e + one2;
         const f32x2 sg = {__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])};
@@ -185,6 +253,11 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
         pv[j] = pr[0]; pv[j + 1] = pr[1];
         dsv[j] = dsr[0]; dsv[j + 1] = dsr[1];
       }
+    }
+    if constexpr (BX::on) {
+      pbase_keep[h8] = pbase;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ds_keep[8 * h8 + j] = dsv[j]; bkt_keep[8 * h8 + j] = bkt[j]; }
     }
     pb[h8] = E::pack8(pv);
     dsb[h8] = E::pack8(dsv);
@@ -221,6 +294,40 @@ HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* 
     u32x2 v2 = {w[2 * (rq & 1)], w[2 * (rq & 1) + 1]};
     *LDS_PTR(u32x2, myds + fold_ds_off(n32, hf + 2 * rq)) = v2;
   }
+  if constexpr (BX::on) {
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+      const float* dsv_ = ds_keep + 8 * h8;
+      const int* bkt_ = bkt_keep + 8 * h8;
+      const int pbase_ = pbase_keep[h8];
+      // d bias = dS' (masked elements carry exact zeros): position histogram (4 consecutive rows x 4 consecutive keys
+      // share a diagonal: three DPP row shifts, one atomic), time histogram (running sum per lane), as hstu_attn_bwd.cuh
+      const int p16 = lane & 15;
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        float t = dsv_[4 * gg + 3];
+#pragma unroll
+        for (int j = 2; j >= 0; --j)
+          t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x101, 0xf, 0xf, true)) + dsv_[4 * gg + j];
+        if (!(BIAS_ABLATE & 1) && t != 0.f) atomicAdd(bx.hpos + pbase_ - 8 * gg, t);
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+          if (!(BIAS_ABLATE & 1) && p16 < j && dsv_[4 * gg + j] != 0.f) atomicAdd(bx.hpos + pbase_ - 8 * gg - j, dsv_[4 * gg + j]);
+      }
+      if (!(BIAS_ABLATE & 2) && bx.bc.lts) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bx.ts_run.add(bkt_[j], dsv_[j]);
+      }
+    }
+  }
+}
+
+template <typename T, int DQK, int DV>
+HSTU_DEV void fold_pair(const HstuAttnParams& p, const MaskCtx& mc, const char* __restrict__ Kw, const char* __restrict__ Vw,
+                        const char* __restrict__ Qs, const char* __restrict__ dOs, char* __restrict__ myds, int i0, int k0, f32x16 (&dk_acc)[DQK / 32],
+                        f32x16 (&dv_acc)[DV / 32], int lane, int dmvm HSTU_TRACE_ARG) {
+  FoldNoBias nb;
+  fold_pair_x<T, DQK, DV, FoldNoBias>(p, mc, Kw, Vw, Qs, dOs, myds, i0, k0, dk_acc, dv_acc, lane, dmvm, nb HSTU_TRACE_PASS);
 }
 
 // Finished dk / dv tiles leave the workgroup in two moves.  (1) PARK: the owner wave writes its transposed
@@ -384,9 +491,9 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 }
 
 // One (user, head) problem `uh` of `total`, on the calling workgroup (all of its LDS).
-template <typename T, int DQK, int DV>
-HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int total, char* smem, int tid, int lane, int wave,
-                          int uh_next, int& pre_lo) {
+template <typename T, int DQK, int DV, typename BX = FoldNoBias>
+HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int total, char* smem, int tid, int lane, int wave,
+                            int uh_next, int& pre_lo, BX& bx) {
   using C = BwdCfg<T, DQK, DV>;
   using F = FoldCfg<T, DQK, DV>;
   static_assert(C::EB == 2, "the folded backward is built for 16-bit I/O");
@@ -503,8 +610,8 @@ HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int to
       // alive across both phases next to the 128 accumulator registers, push the kernel into spilling)
       int lane1 = lane;
       asm volatile("" : "+v"(lane1));
-      fold_pair<T, DQK, DV>(p, mc, Kw, Kw + C::KT, st, st + C::KT, dsbuf + wave * F::DSB, 32 * qt, 32 * kt, dk_acc,
-                            dv_acc, lane1, dmvm HSTU_TRACE_PASS);
+      fold_pair_x<T, DQK, DV, BX>(p, mc, Kw, Kw + C::KT, st, st + C::KT, dsbuf + wave * F::DSB, 32 * qt, 32 * kt, dk_acc,
+                                  dv_acc, lane1, dmvm, bx HSTU_TRACE_PASS);
     }
     HSTU_MARK(13);
     HSTU_MARK(14);
@@ -592,6 +699,13 @@ HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int to
   HSTU_MARK(21);
 }
 
+template <typename T, int DQK, int DV>
+HSTU_DEV void fold_problem(const HstuAttnBwdParams& bp, int tmax, int uh, int total, char* smem, int tid, int lane, int wave,
+                          int uh_next, int& pre_lo) {
+  FoldNoBias nb;
+  fold_problem_x<T, DQK, DV, FoldNoBias>(bp, tmax, uh, total, smem, tid, lane, wave, uh_next, pre_lo, nb);
+}
+
 // FOLD_PERSIST: one workgroup per CU walks the problems blockIdx.x, blockIdx.x + gridDim.x, ... (no workgroup
 // relaunch between two problems of a CU: the dispatch gap, the kernel-argument loads and the wave start-up are paid once)
 template <typename T, int DQK, int DV>
@@ -613,6 +727,66 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   } else {
     int pre_lo = 7;
     fold_problem<T, DQK, DV>(bp, tmax, blockIdx.x, total, smem, tid, lane, wave, -1, pre_lo);
+  }
+}
+
+// Research-path backward (relative position / time bias, hstu_attn_bwd.cuh BIAS) on the folded schedule: one persistent
+// workgroup per CU walks USERS, and for each user its heads.  Per user: tables and timestamps staged once, the time-bucket
+// matrix computed by the first head and kept as bytes; per workgroup: ONE pair of histograms for everything it
+// processes, flushed to its row of `bias_partial` at the end (gridDim rows for the reduce instead of batch x heads).
+// LDS behind the folded kernel's own region: [pos histogram 2N][time histogram (nb+1) x ts_copies][tables][bucket bytes].
+template <typename T, int D>
+__global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void hstu_attn_bwd_fold_bias_kernel(
+    const HstuAttnBwdParams bp, int tmax, float* bias_partial, int ts_copies, int hist_bytes, int table_bytes) {
+  using F = FoldCfg<T, D, D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const HstuAttnParams& p = bp.fwd;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = p.batch * p.heads;
+  FoldBias bx;
+  bx.hpos = (float*)(smem + F::smem_bytes());
+  bx.hts = bx.hpos + 2 * p.max_seq_len;
+  char* const tables = (char*)bx.hpos + hist_bytes;
+  bx.bcache = tables + table_bytes;
+  bx.ts_run.init(bx.hts, ts_copies, lane & (ts_copies - 1));
+  bx.cached = false;
+  const int hist_floats = 2 * p.max_seq_len + (p.num_buckets + 1) * ts_copies;
+  for (int i = tid; i < hist_floats; i += kBwdThreads) bx.hpos[i] = 0.f;
+  int pre_lo = 7;
+  for (int u = blockIdx.x; u < p.batch; u += gridDim.x) {
+    int u_l = u;
+    asm volatile("" : "+s"(u_l));
+    __syncthreads();                       // the previous user's pairs have read their last table entry
+    bx.bc = stage_bias_tables(p, user_of_slot(p, u_l), tables, tid, kBwdThreads);
+    __syncthreads();
+    bx.bc.finish(kBwdWaves);
+    for (int hd = 0; hd < p.heads; ++hd) {
+      const int uh = u_l * p.heads + hd;
+      const int uh_n = hd + 1 < p.heads ? uh + 1 : (u_l + (int)gridDim.x < p.batch ? (u_l + (int)gridDim.x) * p.heads : -1);
+      bx.cached = hd > 0;
+      // (laundering the thread id per problem -- per-thread offsets recomputed instead of living across the loops -- removes
+      // the kernel's 4 spilled registers and costs 4 %: measured, not done)
+      fold_problem_x<T, D, D, FoldBias>(bp, tmax, uh, total, smem, tid, lane, wave, FOLD_PERSIST >= 2 ? uh_n : -1, pre_lo, bx);
+      __syncthreads();
+    }
+  }
+  bx.ts_run.flush();
+  __syncthreads();
+  const float scale_v = attn_scale_of(p);
+  float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
+  const int npos = 2 * p.max_seq_len - 1;
+  for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kBwdThreads) {
+    float v;
+    if (i < npos) {
+      v = bx.hpos[i];
+    } else {
+      v = 0.f;
+      const float* cp = bx.hts + (i - npos) * ts_copies;
+      for (int c = 0; c < ts_copies; ++c) v += cp[c];
+    }
+    row[i] = v * scale_v;
   }
 }
 

@@ -71,7 +71,27 @@ __global__ void probe_glds(const pu32x4* src, const int* perm, pu32x4* out) {
   for (int i = threadIdx.x; i < 256; i += blockDim.x) out[i] = lds[i];
 }
 
+// Fill the whole 160 KiB LDS of every CU with a bit pattern (0xFFFFFFFF = NaN as fp32, bf16 and fp16): kernels that
+// read LDS they never wrote then fail loudly instead of depending on what the previous kernel left behind.
+__global__ __launch_bounds__(256) void probe_poison_lds_kernel(uint32_t pattern, int spin, uint32_t* sink) {
+  extern __shared__ uint32_t poison_lds[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) poison_lds[i] = pattern;
+  __syncthreads();
+  uint32_t x = poison_lds[threadIdx.x];
+  for (int i = 0; i < spin; ++i) x = x * 1664525u + 1013904223u;    // keeps the workgroup resident: one per CU at a time
+  if (x == 0x12345u) sink[0] = x;
+}
+
 extern "C" {
+int probe_poison_lds(uint32_t pattern, void* sink, void* stream) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)probe_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+    attr = true;
+  }
+  hipLaunchKernelGGL(probe_poison_lds_kernel, dim3(2048), dim3(256), 160 * 1024, (hipStream_t)stream, pattern, 20000, (uint32_t*)sink);
+  return (int)hipGetLastError();
+}
 int probe_run_mfma_bf16(const void* A, const void* B, void* C, void* stream) {
   hipLaunchKernelGGL(probe_mfma_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (float*)C);
   return (int)hipGetLastError();
