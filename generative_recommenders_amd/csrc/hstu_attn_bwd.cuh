@@ -254,7 +254,6 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   float* const hpos = (float*)(dsbuf + 2 * nw * C::DSBUF + (nkb > 1 ? kDqScratchBytes : 0));
   float* const hts = hpos + 2 * p.max_seq_len;
   const int hist_floats = 2 * p.max_seq_len + (p.num_buckets + 1) * ts_copies;
-  const int my_copy = lane & (ts_copies - 1);
   if constexpr (BIAS) {
     bc = stage_bias_tables(p, b, (char*)hpos + (hist_floats * 4 + 15) / 16 * 16, tid, kBwdThreads);
     for (int i = tid; i < hist_floats; i += kBwdThreads) hpos[i] = 0.f;
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const bool key_ok = tile_owner && key < len;
   int t_k32 = 0;
   TsRun ts_run;   // running sum of the current time bucket (hstu_common.cuh)
-  ts_run.init(hts, ts_copies, my_copy);
+  ts_run.init(hts, ts_copies);
 
   const int tid_wg = tid;
   for (int hi = 0; hi < n_heads; ++hi) {

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   bx.hts = bx.hpos + 2 * p.max_seq_len;
   char* const tables = (char*)bx.hpos + hist_bytes;
   bx.bcache = tables + table_bytes;
-  bx.ts_run.init(bx.hts, ts_copies, lane & (ts_copies - 1));
+  bx.ts_run.init(bx.hts, ts_copies);
   bx.cached = false;
   const int hist_floats = 2 * p.max_seq_len + (p.num_buckets + 1) * ts_copies;
   for (int i = tid; i < hist_floats; i += kBwdThreads) bx.hpos[i] = 0.f;

@@ -343,27 +343,32 @@ struct BiasCtx {
 // Time-bucket histogram of dS' (research-path backward).  A lane owns ONE key and walks its query rows in order, so the
 // time difference -- and with it the (logarithmic) bucket -- changes only a handful of times per tile: the running sum of
 // the current bucket stays in a register and goes to the LDS histogram when the bucket changes.  The state is the LDS
-// byte address of the current bucket's word (of this lane's histogram copy), so one element costs a shift-add, two
-// compares, one exec-masked ds_add, an add, a select and a move -- no multiply, no nested branches (22 -> 10 instructions).
+// byte offset of the current bucket's word, so one element costs a shift, two compares, one exec-masked ds_add, an add, a
+// select and a move -- no multiply, no nested branches (22 -> 10 instructions).
 struct TsRun {
-  unsigned cur;     // LDS byte address of the running bucket's histogram word
-  unsigned base;    // LDS byte address of bucket 0 of this lane's copy
-  int shift;        // log2(4 * copies)
+  unsigned cur;     // byte offset of the running bucket's word inside this lane's histogram copy: bucket << shift
   float sum;
-  HSTU_DEV void init(const float* hts_lds, int copies, int my_copy) {
-    base = (unsigned)(uintptr_t)LDS_PTR(const float, hts_lds + my_copy);
+  unsigned base;    // wave-uniform: LDS byte address of the histogram
+  int shift;        // wave-uniform: log2(4 * copies)
+  HSTU_DEV void init(const float* hts_lds, int copies) {
+    base = (unsigned)(uintptr_t)LDS_PTR(const float, hts_lds);
     shift = 2 + (31 - __builtin_clz((unsigned)copies));
-    cur = base;
+    cur = 0;
     sum = 0.f;
   }
+  // address of the word: the lane's copy (lane & (copies - 1)) is worked out here, on the rare path, not kept in a register
+  HSTU_DEV __attribute__((address_space(3))) float* word() const {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return (__attribute__((address_space(3))) float*)(uintptr_t)(base + cur + ((lane << 2) & ((1u << shift) - 1u)));
+  }
   HSTU_DEV void flush() {
-    if (sum != 0.f) __hip_atomic_fetch_add((__attribute__((address_space(3))) float*)(uintptr_t)cur, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (sum != 0.f) __hip_atomic_fetch_add(word(), sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     sum = 0.f;
   }
   HSTU_DEV void add(int bkt, float v) {
-    const unsigned a = ((unsigned)bkt << shift) + base;
+    const unsigned a = (unsigned)bkt << shift;
     const bool chg = a != cur;
-    if (chg & (sum != 0.f)) __hip_atomic_fetch_add((__attribute__((address_space(3))) float*)(uintptr_t)cur, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (chg & (sum != 0.f)) __hip_atomic_fetch_add(word(), sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     sum = chg ? v : sum + v;
     cur = a;
   }
