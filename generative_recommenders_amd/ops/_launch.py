@@ -172,6 +172,9 @@ def _shape_params(p: L.HstuAttnParams, dtype, heads, dqk, dv, max_seq_len, alpha
     p.max_attn_len, p.contextual_seq_len, p.min_full_attn_seq_len = int(max_attn_len), int(contextual_seq_len), int(min_full_attn_seq_len)
     p.dtype = L.torch_dtype_code(dtype)
     p.pos_w = 1 if with_bias else None          # only NULL / non-NULL is looked at
+    if with_bias and with_bias != "position":   # True: position AND time tables (128 buckets unless with_bias is a number)
+        p.ts_w, p.timestamps = 1, 1
+        p.num_buckets = 128 if with_bias is True else int(with_bias)
 
 
 def attn_fwd_kernel_name(dtype, dqk, dv, max_seq_len, heads=1, alpha=1.0, max_attn_len=0, contextual_seq_len=0,
