@@ -109,6 +109,52 @@ def test_rel_bias_attention_vs_oracle(dtype, H, A, Ld, n, with_ts):
         _close(ts_w.grad, rts, *btol, f"dts_w[{tag} attention]")
 
 
+@pytest.mark.parametrize("dtype,H,n,B", [(torch.bfloat16, 4, 211, 600), (torch.float16, 2, 100, 900), (torch.bfloat16, 3, 224, 300),
+                                          (torch.bfloat16, 1, 33, 700)])
+def test_folded_bias_backward_many_users_per_workgroup(dtype, H, n, B):
+    """The research-path backward on the folded schedule (hstu_attn_bwd_fold_bias_kernel: head dim 64, 16-bit I/O): more
+    users than CUs, so every persistent workgroup walks several users (tables restaged, bucket bytes recomputed per user,
+    ONE histogram pair per workgroup), every tile count 1..7 incl. the full 224 rows, empty users, odd head counts.
+    Against the fp64 oracle, user by user (timestamps kept off the time-bucket boundaries, as in test_configs_gpu.py: the
+    table gradients are then exact sums and the fp32 gate applies)."""
+    from generative_recommenders_amd.ops import _launch
+    from test_configs_gpu import _timestamps_off_bucket_boundaries
+
+    m = _mods()
+    d = 64
+    assert _launch.attn_bwd_kernel_name(dtype, d, d, n, heads=H, with_bias=True).startswith("hstu_attn_bwd_fold_bias_kernel")
+    torch.manual_seed(n + B)
+    rng = np.random.default_rng(n + B)
+    lengths = rng.integers(0, n + 1, size=B)
+    lengths[:8] = [n, 0, 1, min(32, n), min(33, n), n - 1, 0, n]
+    off = O.complete_cumsum(lengths.astype(np.int64))
+    Lt = int(off[-1])
+    ts = _timestamps_off_bucket_boundaries(rng, B, n)
+    mk = lambda: torch.from_numpy(rng.standard_normal((Lt, H * d)) * 0.3).to(dtype)
+    q, k, v = mk(), mk(), mk()
+    g = torch.from_numpy(rng.standard_normal((Lt, H * d))).to(dtype)
+    bias = m.RelativeBucketedTimeAndPositionBasedBias(n, 128).to(DEV)
+    with torch.no_grad():
+        bias._ts_w.normal_(0, 0.05)
+        bias._pos_w.normal_(0, 0.05)
+    pos_w, ts_w, _, _ = bias.bias_params()
+    qd, kd, vd = (t.to(DEV).requires_grad_() for t in (q, k, v))
+    out = m.hstu_rel_bias_attention(H, d, d, qd, kd, vd, torch.from_numpy(off).to(DEV), torch.from_numpy(ts).to(DEV), n, bias)
+    out.backward(g.to(DEV))
+    pw, tw = pos_w.detach().double().cpu().numpy(), ts_w.detach().double().cpu().numpy()
+    q3, k3, v3 = (t.double().numpy().reshape(Lt, H, d) for t in (q, k, v))
+    ref = O.rel_bias_attention_fwd(n, q3, k3, v3, off, ts, pw, tw)
+    rq, rk, rv, rpos, rts = O.rel_bias_attention_bwd(n, g.double().numpy().reshape(Lt, H, d), q3, k3, v3, off, ts, pw, tw)
+    tol = (3e-2, 6e-3)
+    tag = str(dtype).replace("torch.", "")
+    _close(out, ref.reshape(Lt, -1), *tol, "out")
+    _close(qd.grad, rq.reshape(Lt, -1), *tol, "dq")
+    _close(kd.grad, rk.reshape(Lt, -1), *tol, "dk")
+    _close(vd.grad, rv.reshape(Lt, -1), *tol, "dv")
+    _close(pos_w.grad, rpos, 2e-3, 1e-4, f"dpos_w[{tag} folded]")
+    _close(ts_w.grad, rts, 2e-3, 1e-4, f"dts_w[{tag} folded]")
+
+
 def test_research_layer_forward_backward_runs_and_matches_composition():
     """SequentialTransductionUnitJagged on the fused kernels == the same math composed from the
     oracle pieces (LN without affine -> uvqk -> SiLU on all -> bias attention -> u * LN(attn) -> Linear + x)."""
