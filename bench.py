@@ -427,17 +427,23 @@ def attach_traffic(res, args, att):
             tr = json.load(open(path))
         except Exception:
             continue
-        src = tr.get("source", {"workload": "M-full", "users_per_gpu": 8192, "head_dim": 128, "heads": 4, "dtype": "bf16"})
-        same = (src.get("workload") == args.workload and src.get("users_per_gpu") == args.users_per_gpu
-                and src.get("head_dim") == args.head_dim and src.get("heads") == args.heads and src.get("dtype") == "bf16")
-        if not same:
-            continue
-        res["roofline"]["traffic"] = tr["bwd"]["hbm_bytes_per_launch"]
-        res["roofline"]["traffic_over_algorithmic"] = tr["bwd"]["hbm_bytes_per_launch"] / att["bwd_bytes"]
-        res["roofline"]["traffic_source"] = dict(file="profiles/" + name, kernel=tr["bwd"].get("kernel"), **src)
-        res["roofline_fwd"]["traffic"] = tr["fwd"]["hbm_bytes_per_launch"]
-        res["roofline_fwd"]["traffic_source"] = dict(file="profiles/" + name, kernel=tr["fwd"].get("kernel"), **src)
-        return
+        for ent in tr.get("entries", [tr]):
+            src = ent.get("source", {"workload": "M-full", "users_per_gpu": 8192, "head_dim": 128, "heads": 4, "dtype": "bf16"})
+            same = (src.get("workload") == args.workload and src.get("users_per_gpu") == args.users_per_gpu
+                    and src.get("head_dim") == args.head_dim and src.get("heads") == args.heads and src.get("dtype") == "bf16")
+            if not same:
+                continue
+            dom = ent.get("bwd", ent["fwd"])            # forward-only workloads: the forward is the dominant kernel
+            if dom.get("kernel") not in (res["roofline"].get("kernel"), None):
+                continue                                # the passes were taken on another instantiation: not this run's traffic
+            per = dom["hbm_bytes_per_launch"]
+            res["roofline"]["traffic"] = per
+            res["roofline"]["traffic_over_algorithmic"] = per / res["roofline"]["algorithmic_bytes_per_launch"]
+            res["roofline"]["traffic_source"] = dict(file="profiles/" + name, kernel=dom.get("kernel"), **src)
+            if "roofline_fwd" in res and "bwd" in ent:
+                res["roofline_fwd"]["traffic"] = ent["fwd"]["hbm_bytes_per_launch"]
+                res["roofline_fwd"]["traffic_source"] = dict(file="profiles/" + name, kernel=ent["fwd"].get("kernel"), **src)
+            return
 
 
 def selftest_dist(args, rank, world):
