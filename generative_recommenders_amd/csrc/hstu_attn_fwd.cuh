@@ -157,8 +157,8 @@ HSTU_DEV void store4(char* row_ptr, int d0, float x0, float x1, float x2, float 
   }
 }
 
-template <typename T, int DQK, int DV, bool BIAS = false>
-__global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb) {
+template <typename T, int DQK, int DV, bool BIAS = false, bool HEADS = false>
+__global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb, int bucket_cache_off) {
   using C = FwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n32 = lane & 31, hf = lane >> 5;
+  const int n32 = lane & 31;
 
   // ---- work decode: 8 consecutive (user,head) pairs share a dispatch group so that the
   // query blocks of one (user,head) land on the same XCD (block id mod 8) back to back and
@@ -176,8 +176,15 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   const int grp = bid / (8 * nqb), rem = bid % (8 * nqb);
   const int qb = nqb - 1 - rem / 8;
   const int uh = grp * 8 + (rem & 7);
-  if (uh >= p.batch * p.heads) return;
-  const int b = user_of_slot(p, uh / p.heads), hd = uh % p.heads;
+  // bucket_cache_off > 0 (research-path bias, short sequences): ONE workgroup walks all heads of a (user, query block).
+  // The time bucket of an element depends on the user only; computing it (timestamp read, hardware log2, the exactness
+  // check: ~12 VALU instructions) is 0.64 of the 0.87 ms the bias adds to this kernel at the ML-20M shape, the table
+  // lookups 0.08.  The first head leaves one byte per element in LDS (wave w of query block qb keeps its 4 qb + w + 1
+  // key tiles: 1 KiB each), the other heads read 8 bytes per lane and half tile; the tables are staged once.
+  constexpr bool head_loop = BIAS && HEADS;   // (its own instantiation: the plain bias kernel keeps its 125 registers / 4 waves per SIMD)
+  if (uh >= (head_loop ? p.batch : p.batch * p.heads)) return;
+  const int b = user_of_slot(p, head_loop ? uh : uh / p.heads), hd_first = head_loop ? 0 : uh % p.heads;
+  const int n_heads = head_loop ? p.heads : 1;
 
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
   const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
@@ -227,6 +234,18 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   }
   const int ntiles = (kv_hi - kv_lo + 31) >> 5;
 
+  // bucket bytes of this wave: tiles 0 .. (4 qb + wave) of its query tile, behind those of the waves before it
+  char* const bcache = smem + C::SMEM + bucket_cache_off + (wave * (4 * qb + 1) + ((wave * (wave - 1)) >> 1)) * 1024;
+
+  const int lane_wg = lane;
+  for (int hi = 0; hi < n_heads; ++hi) {
+  const int hd = hd_first + hi;
+  const bool bkt_cached = head_loop && hi > 0;
+  // (the lane id is laundered per head: per-lane LDS offsets are recomputed there instead of being hoisted out of the head
+  // loop and kept alive across the tile loop)
+  int lane_h = lane_wg;
+  if constexpr (head_loop) asm volatile("" : "+v"(lane_h));
+  const int lane = lane_h, n32 = lane & 31, hf = lane >> 5;
   // ---- Q fragment of this wave (B operand of S^T = K Q^T): lane (q = n32, hf) holds
   // elements hf*DQK/2 + 8*kg .. +8 of its row: one contiguous half row per lane.
   Frag qf[C::KG];
@@ -311,16 +330,44 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {   // two halves keep only 8 fp32 temporaries live
         float pv[8];
+        if constexpr (BIAS) {
+#ifndef FWD_BIAS_ABLATE
+#define FWD_BIAS_ABLATE 0   // timing experiments only (wrong results): 1 bucket 0 for every element, 2 no table lookups
+#endif
+          // two straight-line variants of the half tile (wave-uniform choice): buckets read from the user's byte matrix,
+          // or computed and left there -- the bucket goes straight into its element's value, no array of 8 stays live
+          char* const bslot = bcache + (2 * t + h8) * 512 + 8 * lane;
+          if (bkt_cached) {
+            const u32x2 w = *LDS_PTR(const u32x2, bslot);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float x = s[8 * h8 + j] * p.alpha;
-          if constexpr (BIAS) {
-            const int r = 8 * h8 + j;
-            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const int bkt = bc.small ? bc.bucket32(t_q32, bc.t32_at(key)) : bc.bucket(t_q1, bc.ts_at(key));   // wave-uniform choice
-            x += bc.value(bc.pos_index(qi, key), bkt);
+            for (int j = 0; j < 8; ++j) {
+              const int r = 8 * h8 + j;
+              const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+              const int bkt = (int)((w[j >> 2] >> (8 * (j & 3))) & 255u);
+              float x = s[r] * p.alpha;
+              if (!(FWD_BIAS_ABLATE & 2)) x += bc.value(bc.pos_index(qi, key), bkt);
+              pv[j] = x * fast_sigmoid(x);
+            }
+          } else {
+            u32x2 w = {0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int r = 8 * h8 + j;
+              const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+              const int bkt = (FWD_BIAS_ABLATE & 1) ? 0 : (bc.small ? bc.bucket32(t_q32, bc.t32_at(key)) : bc.bucket(t_q1, bc.ts_at(key)));   // wave-uniform choice
+              w[j >> 2] |= (unsigned)bkt << (8 * (j & 3));
+              float x = s[r] * p.alpha;
+              if (!(FWD_BIAS_ABLATE & 2)) x += bc.value(bc.pos_index(qi, key), bkt);
+              pv[j] = x * fast_sigmoid(x);
+            }
+            if (head_loop) *LDS_PTR(u32x2, bslot) = w;
           }
-          pv[j] = x * fast_sigmoid(x);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x = s[8 * h8 + j] * p.alpha;
+            pv[j] = x * fast_sigmoid(x);
+          }
         }
         if (mode == 1) {          // plain causal: key <= query, both in range
 #pragma unroll
@@ -393,7 +440,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         }
       }
       HSTU_MARK(21);
-      return;
+      if (hi + 1 < n_heads) __syncthreads();   // the output tiles (in the ring's place) are read before the next head's K/V land
+      continue;
     }
   }
   if (row_ok) {
@@ -410,6 +458,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     }
   }
   HSTU_MARK(21);
+  if (hi + 1 < n_heads) __syncthreads();
+  }   // heads
 }
 
 }  // namespace hstu
