@@ -189,13 +189,20 @@ def attention_section(args, rank, world, device):
     elapsed = dp.max_over_ranks(t1 - t0, device)
     fwd_ms = _event_ms([(e[0], e[1]) for e in ev])
     bwd_ms = _event_ms([(e[1], e[2]) for e in ev]) if bwd is not None else 0.0
+    # spread of the per-step HIP-event durations (diagnostic only: `value` and the roofline use the K-step totals / means).
+    # The forward of the first process on a fresh box has twice been seen at 2.2 ms instead of 1.37 for a whole run
+    # (DESIGN 5): these fields tell a transient from a slow box.
+    spread = lambda xs: dict(min=round(min(xs), 4), median=round(statistics.median(xs), 4), max=round(max(xs), 4))
+    step_spread = {"fwd_ms": spread([e[0].elapsed_time(e[1]) for e in ev])}
+    if bwd is not None:
+        step_spread["bwd_ms"] = spread([e[1].elapsed_time(e[2]) for e in ev])
     assert finite(out), "non-finite values in the benchmark outputs"
     return dict(
         elapsed=elapsed, users=B, rows=L, total_rows=dp.sum_over_ranks(float(L), device), fwd_ms=fwd_ms, bwd_ms=bwd_ms,
         fwd_gbps=fwd_bytes / fwd_ms / 1e6, bwd_gbps=(bwd_bytes / bwd_ms / 1e6) if bwd_ms else 0.0,
         both_gbps=(fwd_bytes + bwd_bytes) / (fwd_ms + bwd_ms) / 1e6, bwd_bytes=bwd_bytes, fwd_bytes=fwd_bytes,
         tflops=flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12, kernels=kernels, fwd_only=fwd_only,
-        device_ms_per_step=fwd_ms + bwd_ms,
+        device_ms_per_step=fwd_ms + bwd_ms, step_spread=step_spread,
     )
 
 
@@ -523,7 +530,7 @@ def run(args):
                         f"attention {what} via the C ABI" + ("" if args.workload in ("C2", "C5") else ", q/k/v strided views of one fused buffer"),
             "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "sort_by_length": args.sort_by_length, "parallelism": f"dp{world} (no collective: attention has no parameters)",
         },
-        "device_ms_per_step": att["device_ms_per_step"],
+        "device_ms_per_step": att["device_ms_per_step"], "step_spread": att["step_spread"],
     }
     dom = "fwd" if att["fwd_only"] else "bwd"
     res["roofline"] = {
