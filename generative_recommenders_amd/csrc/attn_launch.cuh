@@ -72,6 +72,23 @@ static int bwd_tiles_inst(int max_seq_len, int extra_lds) {
   if (need <= nw) return need < 1 ? 1 : need;        // one key block: no dq accumulation, no scratch
   // several key blocks: the helpers' fp32 dq partials go through a per-wave LDS scratch tile (kDqScratchBytes)
   nw = C::max_tiles(kLdsBudget - extra_lds - kDqScratchBytes);
+  // Away from the diagonal every key tile of the block is active in every step: nw owner waves run one pair each while the
+  // 8 - nw others run the dQ GEMM of the previous query tile, dealt in whole 32-feature blocks (at most DQK/32 helpers
+  // have work).  With the block as large as the LDS allows the owners wait for them most of every step (cycle trace,
+  // N = 1024, 128-wide heads, 5 tiles: owners 6 K cycles, helpers 12.5 K), and a sequence that does not divide into
+  // such blocks ends in a block of one or two tiles whose workgroup is mostly idle waves.  Measured (tools/long_bwd.py
+  // with HSTU_BWD_NW = 3..7 at N = 256 .. 8192): at most 6 tiles per block at head dim 64 (N = 8192: 13.0 -> 10.2 ms),
+  // 5 at 32 (N = 1024: 5.7 -> 4.0 ms), and the tiles spread EVENLY over the fewest blocks that takes (16 tiles at head
+  // dim 128 = 4 x 4 instead of 5 + 5 + 5 + 1: 11.8 -> 9.0 ms).  Dealing single (feature block, key tile) contractions
+  // to the helpers instead -- every one busy -- was measured too and is slower: each partial sum pays the LDS transpose
+  // and 16 atomic instructions of its own.
+  static const int forced = [] { const char* e = getenv("HSTU_BWD_NW"); return e ? atoi(e) : 0; }();
+  const int cap = DQK >= 128 ? 5 : (DQK >= 64 ? 6 : 5);
+  if (nw > cap) nw = cap;
+  if (nw < 1) nw = 1;
+  const int blocks = (need + nw - 1) / nw;
+  nw = (need + blocks - 1) / blocks;
+  if (forced > 0 && forced < nw) nw = forced;
   return nw < 1 ? 1 : nw;
 }
 
