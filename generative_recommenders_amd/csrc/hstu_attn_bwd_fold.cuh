@@ -30,6 +30,10 @@
 #define FOLD_DQ_DEPTH 1   // slots of transposed reads in flight ahead of the MFMAs (2 spills registers)
 #endif
 
+#ifndef FOLD_DQ_EXACT
+#define FOLD_DQ_EXACT 1    // dQ GEMM with exact slot counts for the steps of the 7-tile schedule (0: the static 7 + 4 slots)
+#endif
+
 #ifndef FOLD_SDP_AHEAD
 #define FOLD_SDP_AHEAD 3   // MFMAs whose LDS operands are requested ahead in the S / dP stream
 #endif
@@ -402,8 +406,11 @@ HSTU_DEV typename Elem<T>::Frag tr_frag16(const char* base, int off_lo, int off_
 // query tiles (2 x 2 accumulators of 16 q rows), so every wave runs (a+1) + (b+1) = nt + 1 tile contractions per step
 // whatever the split between the sides.  The dS' tile of key tile t was published by its owner wave: wave t on
 // side A, wave 7 - t on side B.  Fragments of the next contraction are in flight under the MFMAs of this one.
-template <typename T, int DQK, int DV>
-HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv,
+// NA / NB: compile-time slot counts of the two sides (key tiles 0..NA-1 of side A, 0..NB-1 of side B).  The generic
+// instance (7, 4) covers any step by zeroing the dS' fragment of idle slots; the steps of the full-length schedules
+// (7 and 6 tiles) get exact counts: 8 (7) contractions per step instead of 11.
+template <typename T, int DQK, int DV, int NA, int NB>
+HSTU_DEV void fold_dq_slots(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv,
                             const char* __restrict__ dsbuf, int a, int bq, bool b_on, int wave, int64_t off0, int hd,
                             float ds_scale, int lane HSTU_TRACE_ARG) {
   using C = BwdCfg<T, DQK, DV>;
@@ -451,7 +458,7 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) {
 #pragma unroll
-    for (int t = 0; t < (sd ? 4 : F::kMaxTiles); ++t) {
+    for (int t = 0; t < (sd ? NB : NA); ++t) {
       const bool on = ((sd ? on_b : on_a) >> t) & 1u;
       const char* Kt = kv + t * C::PAIR;                          // all 7 slots are always allocated
       const char* ds = dsbuf + (sd ? (kBwdWaves - 1 - t) : t) * F::DSB;
@@ -465,7 +472,7 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   // requested instruction order (hipcc would otherwise, short of registers, serialise read -> wait -> MFMA per
   // slot): the 6 transposed reads of slot s+DEPTH are issued ahead of the MFMA pair of slot s
   if (FOLD_DQ_DEPTH > 0) {
-    constexpr int NSLOT = F::kMaxTiles + 4;
+    constexpr int NSLOT = NA + NB;
     __builtin_amdgcn_sched_group_barrier(0x100, 6 * FOLD_DQ_DEPTH, 0);
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
@@ -488,6 +495,22 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
       gstore16(dqrow + (32 * db + 8 * g) * C::EB, v);
     }
   }
+}
+
+template <typename T, int DQK, int DV>
+HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv,
+                            const char* __restrict__ dsbuf, int a, int bq, bool b_on, int wave, int64_t off0, int hd,
+                            float ds_scale, int lane HSTU_TRACE_ARG) {
+#define HSTU_FOLD_DQ(NA_, NB_) return fold_dq_slots<T, DQK, DV, NA_, NB_>(bp, mc, kv, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane HSTU_TRACE_PASS)
+  const int code = FOLD_DQ_EXACT ? 8 * (a + 1) + (b_on ? bq + 1 : 0) : -1;   // wave-uniform
+  switch (code) {
+    case 8 * 7 + 1: HSTU_FOLD_DQ(7, 1);
+    case 8 * 6 + 2: HSTU_FOLD_DQ(6, 2);
+    case 8 * 5 + 3: HSTU_FOLD_DQ(5, 3);
+    case 8 * 4 + 0: HSTU_FOLD_DQ(4, 0);
+    default: HSTU_FOLD_DQ(7, 4);
+  }
+#undef HSTU_FOLD_DQ
 }
 
 // One (user, head) problem `uh` of `total`, on the calling workgroup (all of its LDS).

@@ -21,6 +21,10 @@
 #pragma once
 #include "hstu_attn_bwd_fold.cuh"
 
+#ifndef QUAD_ABLATE
+#define QUAD_ABLATE 0      // timing experiments only (WRONG results): 1 no dQ stores, 2 no dk/dv stores, 16 no K/V DMA, 32 no dQ
+#endif                     // GEMM, 64 no pairs
+
 namespace hstu {
 
 constexpr int kQuadWaves = 4;
@@ -55,16 +59,17 @@ HSTU_DEV void quad_copy_out(const char* __restrict__ tile, char* gtile, int64_t 
   for (int u = tid; u < 32 * UPR; u += kQuadThreads) {
     const int row = u / UPR, unit = u % UPR;
     const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, unit));
-    if (row < rows_valid) gstore16(gtile + row * row_stride_bytes + unit * 16, v);
+    if (row < rows_valid && (!(QUAD_ABLATE & 2) || row_stride_bytes == -12345)) gstore16(gtile + row * row_stride_bytes + unit * 16, v);
   }
 }
 
 // dQ of query tile qt: dQ^T[d][q] = sum over key tiles of K_t^T[d][key] dS'_t^T[key][q] (16x16x32 MFMA, one key tile =
-// one contraction).  Wave w owns the 32 feature columns [32 (w & 1), +32) of query rows [16 (w >> 1), +16): two
+// one contraction; NSLOT = qt + 1 of them, a compile-time count: the causal triangle needs 28 contractions per problem, a
+// static 7-slot loop with zeroed idle slots runs 49).  Wave w owns the 32 feature columns [32 (w & 1), +32) of query rows [16 (w >> 1), +16): two
 // MFMAs whose A rows interleave the features in groups of 4, so that a lane ends up with 8 consecutive features of
 // one query row (one 16-byte store; see fold_dq_phase).  Static 7-slot loop, idle slots get a zeroed dS' fragment.
-template <typename T, int D>
-HSTU_DEV void quad_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv,
+template <typename T, int D, int NSLOT>
+HSTU_DEV void quad_dq_slots(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv,
                             const char* __restrict__ dsbuf, int qt, int wave, int64_t off0, int hd, float ds_scale, int lane) {
   using C = BwdCfg<T, D, D>;
   using Q = QuadCfg<T, D>;
@@ -87,7 +92,7 @@ HSTU_DEV void quad_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int t = 0; t < Q::kMaxTiles; ++t) {
+  for (int t = 0; t < NSLOT; ++t) {
     const char* Kt = kv + t * C::PAIR;
     const Frag fk0 = tr_frag16<T>(Kt, k0_lo, k0_hi), fk1 = tr_frag16<T>(Kt, k1_lo, k1_hi);
     Frag fd = tr_frag16<T>(dsbuf + t * Q::DSB, d_lo, d_hi);
@@ -98,18 +103,32 @@ HSTU_DEV void quad_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   // requested order: the 6 transposed reads of slot s+1 ahead of the MFMA pair of slot s
   __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
-  for (int sl = 0; sl < Q::kMaxTiles; ++sl) {
-    if (sl + 1 < Q::kMaxTiles) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+  for (int sl = 0; sl < NSLOT; ++sl) {
+    if (sl + 1 < NSLOT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
   }
   // C layout of MFMA h: column i16 = query row, register r = feature 32 db + 8 g + 4 h + r
   const int qrow = 32 * qt + 16 * qb + i16;
-  if (qrow < mc.len) {
+  if (qrow < mc.len && (!(QUAD_ABLATE & 1) || bp.total_rows == -12345)) {
     char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
     u32x4 v = {E::pk2(acc[0][0] * ds_scale, acc[0][1] * ds_scale), E::pk2(acc[0][2] * ds_scale, acc[0][3] * ds_scale),
                E::pk2(acc[1][0] * ds_scale, acc[1][1] * ds_scale), E::pk2(acc[1][2] * ds_scale, acc[1][3] * ds_scale)};
     gstore16(dqrow + (32 * db + 8 * g) * C::EB, v);
+  }
+}
+
+template <typename T, int D>
+HSTU_DEV void quad_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv,
+                            const char* __restrict__ dsbuf, int qt, int wave, int64_t off0, int hd, float ds_scale, int lane) {
+  switch (qt) {   // (wave-uniform)
+    case 0: return quad_dq_slots<T, D, 1>(bp, mc, kv, dsbuf, qt, wave, off0, hd, ds_scale, lane);
+    case 1: return quad_dq_slots<T, D, 2>(bp, mc, kv, dsbuf, qt, wave, off0, hd, ds_scale, lane);
+    case 2: return quad_dq_slots<T, D, 3>(bp, mc, kv, dsbuf, qt, wave, off0, hd, ds_scale, lane);
+    case 3: return quad_dq_slots<T, D, 4>(bp, mc, kv, dsbuf, qt, wave, off0, hd, ds_scale, lane);
+    case 4: return quad_dq_slots<T, D, 5>(bp, mc, kv, dsbuf, qt, wave, off0, hd, ds_scale, lane);
+    case 5: return quad_dq_slots<T, D, 6>(bp, mc, kv, dsbuf, qt, wave, off0, hd, ds_scale, lane);
+    default: return quad_dq_slots<T, D, 7>(bp, mc, kv, dsbuf, qt, wave, off0, hd, ds_scale, lane);
   }
 }
 
@@ -148,7 +167,7 @@ HSTU_DEV void quad_problem(const HstuAttnBwdParams& bp, int tmax, int uh, char* 
     quad_tile_dma<T, D>(stage + C::KT, dobase, do_rs, 32 * qt, len, wave, lane);
   };
   // ---- prologue: the whole K/V block and the first query tile, all by LDS-DMA
-  for (int t = 0; t < nt; ++t) {
+  for (int t = 0; t < ((QUAD_ABLATE & 16) ? 0 : nt); ++t) {
     char* dst = smem + t * C::PAIR;
     quad_tile_dma<T, D>(dst, kbase, k_rs, 32 * t, len, wave, lane);
     quad_tile_dma<T, D>(dst + C::KT, vbase, v_rs, 32 * t, len, wave, lane);
@@ -191,13 +210,13 @@ HSTU_DEV void quad_problem(const HstuAttnBwdParams& bp, int tmax, int uh, char* 
       else if (fin == tB) fold_park_tile<T, D>(dkB, ds_scale, smem + fin * C::PAIR, lane3);
     }
     // ---- phase 1: the pairs (i, t) of this wave's tiles
-    if (tA <= i && (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 32 * tA, 32))) {
+    if (!(QUAD_ABLATE & 64) && tA <= i && (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 32 * tA, 32))) {
       const char* Kw = smem + tA * C::PAIR;
       int lane1 = lane;
       asm volatile("" : "+v"(lane1));
       fold_pair<T, D, D>(p, mc, Kw, Kw + C::KT, stage, stage + C::KT, dsbuf + tA * Q::DSB, 32 * i, 32 * tA, dkA, dvA, lane1, dmvm HSTU_TRACE_PASS);
     }
-    if (tB >= 0 && tB <= i && (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 32 * tB, 32))) {
+    if (!(QUAD_ABLATE & 64) && tB >= 0 && tB <= i && (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 32 * tB, 32))) {
       const char* Kw = smem + tB * C::PAIR;
       int lane1 = lane;
       asm volatile("" : "+v"(lane1));
@@ -212,7 +231,7 @@ HSTU_DEV void quad_problem(const HstuAttnBwdParams& bp, int tmax, int uh, char* 
     // ---- phase 2: dQ of query tile i
     int lane2 = lane;
     asm volatile("" : "+v"(lane2));
-    quad_dq_phase<T, D>(bp, mc, smem, dsbuf, i, wave, off0, hd, ds_scale, lane2);
+    if (!(QUAD_ABLATE & 32)) quad_dq_phase<T, D>(bp, mc, smem, dsbuf, i, wave, off0, hd, ds_scale, lane2);
     // key tile i is final: V tiles are read by their owner's pairs only, and this was its last one
     {
       int lane3 = lane;

@@ -64,7 +64,9 @@ def test_no_kernel_spills_or_uses_scratch():
     # removes the spills and was measured 4 % SLOWER, so the 4 are accepted -- and bounded here.
     accepted = ("hstu_attn_bwd_kernelIfLi128ELi128E", "hstu_attn_bwd_kernelIfLi64ELi128ELb0E")
     # The general research-path backward at 128 x 128 (no research configuration has heads that wide) keeps one.
-    bounded = {"hstu_attn_bwd_fold_bias_kernel": 4, "hstu_attn_bwd_kernelIDF16bLi128ELi128ELb1E": 1, "hstu_attn_bwd_kernelIDF16_Li128ELi128ELb1E": 1}
+    # The folded backward at 128 x 128 spills 2 registers since its dQ GEMM got exact slot counts per step (four more copies
+    # of that phase): measured 1.4 % FASTER than the spill-free static-slot version on the same box (tools/ab_bwd.py).
+    bounded = {"hstu_attn_bwd_fold_bias_kernel": 4, "hstu_attn_bwd_fold_kernelIDF16bLi128ELi128E": 2, "hstu_attn_bwd_fold_kernelIDF16_Li128ELi128E": 2, "hstu_attn_bwd_kernelIDF16bLi128ELi128ELb1E": 1, "hstu_attn_bwd_kernelIDF16_Li128ELi128ELb1E": 1}
     bad = {k: v for k, v in ks.items() if (v["spill"] or v["scratch"]) and "hstu" in k and not any(a in k for a in accepted)
            and not any(b in k and v["spill"] <= n for b, n in bounded.items())}
     assert not bad, f"kernels with register spills / scratch: {bad}"
