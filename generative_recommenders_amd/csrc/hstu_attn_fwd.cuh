@@ -23,6 +23,9 @@
 namespace hstu {
 
 constexpr int kFwdThreads = 256;
+#ifndef FWD_ABLATE
+#define FWD_ABLATE 0   // timing experiments only (wrong results): 1 no output stores, 2 no MFMA / element-wise work (loads and barriers only), 4 no K/V loads
+#endif
 #ifndef HSTU_FWD_MIN_WAVES
 #define HSTU_FWD_MIN_WAVES 2
 #endif
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   // ---- K/V tiles stream through an NS-deep LDS ring filled by LDS-DMA: tiles t+1 .. t+NS-1 are in
   // flight while tile t is computed; one raw barrier per tile, loads are never drained in the loop
   auto issue_tile = [&](int t) {
+    if (FWD_ABLATE & 4) return;   // (timing experiment: no K/V loads)
     char* st = smem + (t % C::NS) * C::STAGE;
     tile_dma<T, DQK>(st, kbase, k_rs, kv_lo + 32 * t, len, p.dqk, wave, 4, lane);
     tile_dma<T, DV>(st + C::KT, vbase, v_rs, kv_lo + 32 * t, len, p.dv, wave, 4, lane);
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       tile_act = mc.pair_may_be_active(i0w, 32, j0, 32);
       tile_full = tile_act && mc.pair_fully_valid(i0w, 32, j0, 32);
     }
-    if (wave_active && tile_act) {
+    if (wave_active && tile_act && !(FWD_ABLATE & 2)) {
       const char* Kt = smem + (t % C::NS) * C::STAGE;
       const char* Vt = Kt + C::KT;
       // ONE accumulator chain: back-to-back dependent MFMAs forward their result, and the VALU cycles a second chain
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
           const int idx = i * 64 + lane;
           const int row = idx / C::UPR_V, unit = idx % C::UPR_V;
           const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<C::UPR_V>(row, unit));
-          if (row < rows_valid) gstore16_nt(obase + (int64_t)row * p.o_row_stride * C::EB + unit * 16, v);
+          if (row < rows_valid && (!(FWD_ABLATE & 1) || p.batch == -12345)) gstore16_nt(obase + (int64_t)row * p.o_row_stride * C::EB + unit * 16, v);
         }
       }
       HSTU_MARK(21);
