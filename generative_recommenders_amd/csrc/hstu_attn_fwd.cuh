@@ -268,6 +268,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     }
   }
 
+  // (issuing these Q loads, then the first K/V tiles, and only then waiting for the Q fragments -- the Q round trip under
+  // the DMA's instead of in front of it -- was measured: 1.391 -> 1.420 ms at head dim 128, no change at 64)
   HSTU_MARK(2);
   const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
   const char* vbase = (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * C::EB;
