@@ -124,6 +124,8 @@ def build_torch_ops(verbose: bool = False) -> str:
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     tdir = os.path.dirname(torch.__file__)
+    # (the two -D switches are what PyTorch-ROCm's OWN headers need to be compiled by a plain host compiler -- the flags
+    # torch.utils.cpp_extension passes on ROCm; nothing in this repository is conditional on them)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
            f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include", src, "-o", out,
