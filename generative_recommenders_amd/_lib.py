@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime ou
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSTU_HIP_LIBRARY overrides the in-tree build (A/B measurements of kernel variants, packaged installs)
 LIB_PATH = os.environ.get("HSTU_HIP_LIBRARY") or os.path.join(_HERE, "libhstu_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
 HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
@@ -84,6 +84,8 @@ SIGNATURES = {
     "hstu_norm_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "hstu_norm_mul_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _int, _int, _int, _vp]),
     "hstu_norm_mul_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _int, _int, _int, _vp]),
+    "hstu_norm_mul_dropout_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _int, _int, _f32, C.c_uint64, _int, _vp]),
+    "hstu_norm_mul_dropout_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _int, _int, _f32, C.c_uint64, _int, _vp]),
     "hstu_silu_fwd": (_int, [_vp, _vp, _i64, _i32, _i64, _i64, _int, _vp]),
     "hstu_silu_bwd": (_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _int, _vp]),
     "hstu_add_ts_pos_emb_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _int, _int, _vp]),
@@ -111,7 +113,11 @@ def build(verbose: bool = False) -> str:
         print(res.stderr[-4000:])
     if res.returncode != 0:
         raise HstuLibraryError("building libhstu_hip.so failed (see output above)")
-    build_torch_ops(verbose)
+    try:
+        build_torch_ops(verbose)
+    except HstuLibraryError as e:   # the C-ABI library is usable without the torch.ops.hstu registration
+        import warnings
+        warnings.warn(f"libhstu_hip.so built, but {e}; torch.ops.hstu.* will not be available")
     return LIB_PATH
 
 
@@ -120,8 +126,13 @@ def build_torch_ops(verbose: bool = False) -> str:
     with CUDA + Meta kernels on top of the C ABI (csrc/torch_ops/hstu_torch_ops.cpp).  Skipped when up to date."""
     src = os.path.join(_HERE, "csrc", "torch_ops", "hstu_torch_ops.cpp")
     out = os.path.join(_HERE, "libhstu_torch_ops.so")
-    deps = [src, os.path.join(_HERE, "..", "include", "hstu_hip.h")]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    # rebuilt when the source, the header, the core library it links (HstuAttnParams is passed by pointer: a stale pair
+    # would read garbage fields) or the torch it was compiled against changes
+    deps = [src, os.path.join(_HERE, "..", "include", "hstu_hip.h"), os.path.join(_HERE, "libhstu_hip.so")]
+    stamp = out + ".torch_version"
+    stamped = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if (os.path.exists(out) and stamped == torch.__version__
+            and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps if os.path.exists(d))):
         return out
     tdir = os.path.dirname(torch.__file__)
     # (the two -D switches are what PyTorch-ROCm's OWN headers need to be compiled by a plain host compiler -- the flags
@@ -137,6 +148,8 @@ def build_torch_ops(verbose: bool = False) -> str:
         print(res.stderr[-4000:])
     if res.returncode != 0:
         raise HstuLibraryError("building libhstu_torch_ops.so failed (see output above)")
+    with open(stamp, "w") as f:
+        f.write(torch.__version__)
     return out
 
 
@@ -147,8 +160,9 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise HstuLibraryError(
-            f"{LIB_PATH} not found: build it with `make -C generative_recommenders_amd/csrc` "
-            "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback for the HSTU ops."
+            f"{LIB_PATH} not found: build it with `python -c 'from generative_recommenders_amd import _lib; _lib.build()'` "
+            "(= __graft_entry__.build(): libhstu_hip.so AND libhstu_torch_ops.so).  There is no CPU / PyTorch fallback "
+            "for the HSTU ops."
         )
     try:
         handle = C.CDLL(LIB_PATH)

@@ -29,6 +29,15 @@ constexpr int kFwdThreads = 256;
 #ifndef HSTU_FWD_MIN_WAVES
 #define HSTU_FWD_MIN_WAVES 2
 #endif
+#ifndef FWD_DMA_FAST
+#define FWD_DMA_FAST 1      // K/V LDS-DMA source addresses: uniform base + 32-bit lane offset from a per-lane plan (3 VALU per chunk)
+#endif
+#ifndef FWD_EPI_FREE
+#define FWD_EPI_FREE 1      // epilogue without a workgroup barrier: output tiles are parked in the ring slots that are dead after the last step
+#endif
+#ifndef FWD_EPI_SWAP
+#define FWD_EPI_SWAP 1      // parked output tile: 8-byte halves of a unit swapped on rows with bit 1 set (conflict-free ds_write_b64)
+#endif
 constexpr int kFwdRowsPerBlock = 128;
 
 template <typename T, int DQK, int DV>
@@ -110,6 +119,37 @@ HSTU_DEV void tile_dma(char* tile, const char* base, int64_t row_stride_bytes, i
     const char* g = base + (int64_t)grow * row_stride_bytes + gunit * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)(tile + c * 1024), 16, 0, 0);
+  }
+}
+
+// The same with the lane-constant part of the address planned ahead (NI chunks per wave: c = wave + i nwaves): the lane's row
+// inside the tile and the byte offset of its (swizzled, clamped) unit.  A chunk then costs add + min + a 24-bit multiply-add,
+// and the load takes its 64-bit base from SGPRs (global_load_lds ... v_off32, s[base]).
+template <int NI> struct DmaPlan { int rl[NI]; uint32_t uo[NI]; };
+
+template <typename T, int D, int NI>
+HSTU_DEV void dma_plan(DmaPlan<NI>& pl, int real_d, int wave, int nwaves, int lane) {
+  constexpr int UPR = D * Elem<T>::kBytes / 16;
+  constexpr int EPU = 16 / Elem<T>::kBytes;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int pidx = (wave + i * nwaves) * 64 + lane;
+    const int row = pidx / UPR, slot = pidx % UPR;
+    const int unit = slot ^ swz<UPR>(row);
+    pl.rl[i] = row;
+    pl.uo[i] = (unit * EPU < real_d) ? unit * 16 : 0;
+  }
+}
+
+template <int NI>
+HSTU_DEV void tile_dma_fast(char* tile, const char* base, uint32_t row_stride_bytes, int row0, int len, const DmaPlan<NI>& pl,
+                            int wave, int nwaves) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t grow = (uint32_t)min(row0 + pl.rl[i], len - 1);
+    const uint32_t off = __umul24(grow, row_stride_bytes) + pl.uo[i];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                     (__attribute__((address_space(3))) void*)(tile + (wave + i * nwaves) * 1024), 16, 0, 0);
   }
 }
 
@@ -200,7 +240,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   const MaskCtx mc = make_mask_ctx(p, b, len);
   const float scale_v = attn_scale_of(p);
 #ifdef HSTU_TRACE
-  HSTU_TRACE_DECL(g_hstu_trace_fwd, g_hstu_trace_fwd != nullptr && blockIdx.x == 4096);
+  // blocks 4096 / 4104: the heavy and the light query block of one (user, head); rows 0-3 / 4-7 of the trace buffer
+  HSTU_TRACE_DECL(g_hstu_trace_fwd + (blockIdx.x == 4104 ? 4 * 256 : 0), g_hstu_trace_fwd != nullptr && (blockIdx.x == 4096 || blockIdx.x == 4104));
 #endif
   HSTU_MARK(1);
   const int r0 = q0 + 32 * wave;                 // first q row of this wave
@@ -283,9 +324,29 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
 
   // ---- K/V tiles stream through an NS-deep LDS ring filled by LDS-DMA: tiles t+1 .. t+NS-1 are in
   // flight while tile t is computed; one raw barrier per tile, loads are never drained in the loop
+  // The source address of a chunk is (uniform tile base) + (row of the lane) x (row stride) + (swizzled unit) x 16.  Written
+  // naively that is ~20 VALU instructions per chunk -- a 64-bit multiply-add among them -- i.e. 80 per key tile and wave next
+  // to the ~90 of the tile's element-wise block, in a kernel whose SIMDs are VALU-issue bound (`profiles/r03_fwd_valu.md`).
+  // The lane's row inside the tile and its unit's byte offset never change: they are planned once per head, and a chunk
+  // costs an add, a min and one 24-bit multiply-add into a 32-bit offset from the head's (scalar) base pointer.  Needs the
+  // user's rows to span < 4 GiB and strides < 16 MiB (else the general path).
+  constexpr int NIK = C::COUNTED ? C::NCH_K / 4 : 1, NIV = C::COUNTED ? C::NCH_V / 4 : 1;
+  const bool dma_fast = FWD_DMA_FAST && C::COUNTED && k_rs < (1 << 24) && v_rs < (1 << 24) &&
+                        (int64_t)len * k_rs < (1LL << 32) && (int64_t)len * v_rs < (1LL << 32);   // workgroup-uniform
+  DmaPlan<NIK> plk;
+  DmaPlan<NIV> plv;
+  if (dma_fast) {
+    dma_plan<T, DQK, NIK>(plk, p.dqk, wave, 4, lane);
+    dma_plan<T, DV, NIV>(plv, p.dv, wave, 4, lane);
+  }
   auto issue_tile = [&](int t) {
     if (FWD_ABLATE & 4) return;   // (timing experiment: no K/V loads)
     char* st = smem + (t % C::NS) * C::STAGE;
+    if (dma_fast) {
+      tile_dma_fast<NIK>(st, kbase, (uint32_t)k_rs, kv_lo + 32 * t, len, plk, wave, 4);
+      tile_dma_fast<NIV>(st + C::KT, vbase, (uint32_t)v_rs, kv_lo + 32 * t, len, plv, wave, 4);
+      return;
+    }
     tile_dma<T, DQK>(st, kbase, k_rs, kv_lo + 32 * t, len, p.dqk, wave, 4, lane);
     tile_dma<T, DV>(st + C::KT, vbase, v_rs, kv_lo + 32 * t, len, p.dv, wave, 4, lane);
   };
@@ -424,8 +485,23 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   // storing the accumulators directly is DV/4 dwordx2 stores per lane that touch 64 rows each (store-issue bound).
   if constexpr (C::EB == 2 && C::SMEM >= 4 * C::VT) {
     if (p.dv == DV) {     // wave-uniform
-      __syncthreads();    // every wave is done with the ring
-      char* tile = smem + wave * C::VT;
+      // Where a wave parks its tile.  After the barrier of the LAST step every wave has finished the step before it, so of
+      // the ring's three slots only the last tile's is still being read: the two others (a K/V pair = two output tiles
+      // each) are dead and each wave has a private tile there -- no workgroup barrier, a wave that is done early (the
+      // causal triangle) stores its rows while the others still compute.  Otherwise: barrier, then the ring's start.
+      constexpr bool epi_free = FWD_EPI_FREE && C::NS == 3 && C::STAGE >= 2 * C::VT && kFwdThreads / 64 <= 4;
+      char* tile;
+      if constexpr (epi_free) {
+        const int dead = ((ntiles > 0 ? ntiles - 1 : 0) + 1 + (wave >> 1)) % C::NS;   // the slots after the last tile's, cyclically
+        tile = smem + dead * C::STAGE + (wave & 1) * C::VT;
+      } else {
+        __syncthreads();    // every wave is done with the ring
+        tile = smem + wave * C::VT;
+      }
+      // (8-byte halves: the 16 lanes of a ds_write_b64 group -- rows r..r+15 of one unit column, one hf -- cover each
+      // 16-byte slot class mod 8 twice; with the half flipped on rows whose swizzle has bit 3 set, i.e. row bit 1, the two
+      // land in different halves of the 128-byte write window: no bank conflict.  The copy-out flips them back.)
+      const int hsw = FWD_EPI_SWAP ? ((n32 >> 1) & 1) : 0;
       if (wave_active) {
 #pragma unroll
         for (int d = 0; d < C::DB; ++d)
@@ -433,7 +509,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
           for (int rq = 0; rq < 4; ++rq) {
             u32x2 v = {E::pk2(oacc[d][4 * rq] * scale_v, oacc[d][4 * rq + 1] * scale_v),
                        E::pk2(oacc[d][4 * rq + 2] * scale_v, oacc[d][4 * rq + 3] * scale_v)};
-            *LDS_PTR(u32x2, tile + tile_off<C::UPR_V>(n32, 4 * d + rq) + 8 * hf) = v;
+            *LDS_PTR(u32x2, tile + tile_off<C::UPR_V>(n32, 4 * d + rq) + 8 * (hf ^ hsw)) = v;
           }
         char* obase = (char*)p.out + ((q_base + r0) * p.o_row_stride + (int64_t)hd * p.o_head_stride) * C::EB;
         const int rows_valid = nq_rows - r0;
@@ -441,7 +517,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         for (int i = 0; i < 32 * C::UPR_V / 64; ++i) {
           const int idx = i * 64 + lane;
           const int row = idx / C::UPR_V, unit = idx % C::UPR_V;
-          const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<C::UPR_V>(row, unit));
+          u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<C::UPR_V>(row, unit));
+          if (FWD_EPI_SWAP && ((row >> 1) & 1)) v = u32x4{v[2], v[3], v[0], v[1]};
           if (row < rows_valid && (!(FWD_ABLATE & 1) || p.batch == -12345)) gstore16_nt(obase + (int64_t)row * p.o_row_stride * C::EB + unit * 16, v);
         }
       }

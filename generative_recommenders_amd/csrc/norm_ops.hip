@@ -68,6 +68,55 @@ HSTU_DEV float wave_sum(float x) {
   return x;
 }
 
+// ------------------------------------------------------------------ fused dropout of the output stage
+// Replaces the Philox dropout inside _ln_mul_dropout_fwd / _group_norm_mul_dropout_fwd (triton_hstu_linear.py:101-120,
+// 631-652; backward :196-215, :718-738): the mask of an output element is a pure function of (seed, element index in the
+// (rows, out_stride) output), so the backward -- and the forward recompute of y -- regenerate it instead of storing it.
+// One hash gives 32 bits = two 16-bit uniforms for the elements 2j and 2j+1: keep iff r16 >= thr, thr = round(p 65536),
+// survivors scaled by 65536 / (65536 - thr) (the exact inverse of the keep probability).  The hash is two rounds of
+// 32-bit multiply-xorshift finalisers (murmur3 fmix32, then lowbias32) with one seed word folded in before each;
+// oracle/hstu_oracle.py::dropout_keep_mask restates it bit for bit.
+struct DropCtx {
+  uint32_t thr;        // 0 = no dropout
+  float scale;
+  uint32_t s0, s1;
+};
+HSTU_DEV uint32_t drop_hash(uint32_t lo, uint32_t hi, uint32_t s0, uint32_t s1) {
+  uint32_t h = lo ^ s0;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  h ^= s1 + hi * 0x9e3779b9u;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+// v[i] *= keep(e0 + i) ? scale : 0 for i < VEC; e0 = index of v[0] in the output tensor (even when VEC > 1)
+template <typename T, int VEC>
+HSTU_DEV void drop_apply(RowVec<T, VEC>& r, int64_t e0, const DropCtx& dc) {
+  if constexpr (VEC == 1) {
+    const uint64_t pe = (uint64_t)e0 >> 1;
+    const uint32_t h = drop_hash((uint32_t)pe, (uint32_t)(pe >> 32), dc.s0, dc.s1);
+    const uint32_t r16 = (e0 & 1) ? (h >> 16) : (h & 0xffffu);
+    r.v[0] = r16 >= dc.thr ? r.v[0] * dc.scale : 0.f;
+  } else {
+    const uint64_t pe0 = (uint64_t)e0 >> 1;
+#pragma unroll
+    for (int j = 0; j < VEC / 2; ++j) {
+      const uint64_t pe = pe0 + j;
+      const uint32_t h = drop_hash((uint32_t)pe, (uint32_t)(pe >> 32), dc.s0, dc.s1);
+      r.v[2 * j] = (h & 0xffffu) >= dc.thr ? r.v[2 * j] * dc.scale : 0.f;
+      r.v[2 * j + 1] = (h >> 16) >= dc.thr ? r.v[2 * j + 1] * dc.scale : 0.f;
+    }
+  }
+}
+static DropCtx make_drop_ctx(float ratio, uint64_t seed) {
+  DropCtx dc;
+  double t = (double)ratio * 65536.0 + 0.5;
+  dc.thr = ratio > 0.f ? (uint32_t)(t < 1.0 ? 1.0 : (t > 65535.0 ? 65535.0 : t)) : 0u;
+  dc.scale = 65536.0f / (float)(65536u - dc.thr);
+  dc.s0 = (uint32_t)seed;
+  dc.s1 = (uint32_t)(seed >> 32);
+  return dc;
+}
+
 // ------------------------------------------------------------------ layer norm
 template <typename T, int VEC>
 __global__ __launch_bounds__(kNormThreads) void layer_norm_fwd_kernel(const T* x, const T* w, const T* b, T* y,
@@ -224,7 +273,7 @@ template <typename T, int VEC, bool GN>
 __global__ __launch_bounds__(kNormThreads) void norm_mul_fwd_kernel(const T* attn, const T* u, const T* w, const T* b,
                                                                     T* y, float* mean_out, float* rstd_out,
                                                                     int64_t rows, int heads, int hdim, float eps,
-                                                                    int concat) {
+                                                                    int concat, DropCtx dc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = heads * hdim;
   const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
@@ -275,10 +324,17 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_fwd_kernel(const T* att
           }
           T* yrow = y + row * ostride;
           if (concat) {
-            store_vec<T, VEC>(uv[k], yrow + c);
-            store_vec<T, VEC>(xv[k], yrow + dim + c);
+            RowVec<T, VEC> ud = uv[k], xd = xv[k];
+            if (dc.thr) {   // kernel-uniform
+              drop_apply<T, VEC>(ud, row * ostride + c, dc);
+              drop_apply<T, VEC>(xd, row * ostride + dim + c, dc);
+              drop_apply<T, VEC>(o, row * ostride + 2 * dim + c, dc);
+            }
+            store_vec<T, VEC>(ud, yrow + c);
+            store_vec<T, VEC>(xd, yrow + dim + c);
             store_vec<T, VEC>(o, yrow + 2 * dim + c);
           } else {
+            if (dc.thr) drop_apply<T, VEC>(o, row * ostride + c, dc);
             store_vec<T, VEC>(o, yrow + c);
           }
         }
@@ -298,7 +354,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_kernel(const T* dy,
                                                                     const T* b, const float* mean_in,
                                                                     const float* rstd_in, T* dattn, T* du,
                                                                     float* partial, int64_t rows, int heads, int hdim,
-                                                                    int concat) {
+                                                                    int concat, DropCtx dc) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = heads * hdim;
@@ -325,6 +381,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_kernel(const T* dy,
       load_vec<T, VEC>(xv[k], attn + row * dim + c, ok);
       load_vec<T, VEC>(uv[k], u + row * dim + c, ok);
       load_vec<T, VEC>(gy[k], dyrow + (concat ? 2 * dim : 0) + c, ok);
+      if (dc.thr && ok) drop_apply<T, VEC>(gy[k], row * istride + (concat ? 2 * dim : 0) + c, dc);   // d y3 -> d y: same mask, same scale
     }
 #pragma unroll
     for (int gi = 0; gi < 16; ++gi) {
@@ -366,6 +423,10 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_kernel(const T* dy,
             if (concat) {
               load_vec<T, VEC>(e1, dyrow + c, true);          // d u   from the concat slot
               load_vec<T, VEC>(e2, dyrow + dim + c, true);    // d attn from the concat slot
+              if (dc.thr) {
+                drop_apply<T, VEC>(e1, row * istride + c, dc);
+                drop_apply<T, VEC>(e2, row * istride + dim + c, dc);
+              }
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -416,7 +477,7 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(kNormThreads) void norm_mul_fwd_gn_kernel(const T* attn, const T* u, const T* w, const T* b,
                                                                        T* y, float* mean_out, float* rstd_out,
                                                                        int64_t rows, int heads, int hdim, float eps,
-                                                                       int concat) {
+                                                                       int concat, DropCtx dc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = heads * hdim;
   const int nch = (dim + 64 * VEC - 1) / (64 * VEC);
@@ -453,10 +514,16 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_fwd_gn_kernel(const T* 
           for (int i = 0; i < VEC; ++i) o.v[i] = uv[k].v[i] * ((xv[k].v[i] - mean) * rstd * gw + gb);
           T* yrow = y + row * ostride;
           if (concat) {
+            if (dc.thr) {   // kernel-uniform
+              drop_apply<T, VEC>(uv[k], row * ostride + c, dc);
+              drop_apply<T, VEC>(xv[k], row * ostride + dim + c, dc);
+              drop_apply<T, VEC>(o, row * ostride + 2 * dim + c, dc);
+            }
             store_vec<T, VEC>(uv[k], yrow + c);
             store_vec<T, VEC>(xv[k], yrow + dim + c);
             store_vec<T, VEC>(o, yrow + 2 * dim + c);
           } else {
+            if (dc.thr) drop_apply<T, VEC>(o, row * ostride + c, dc);
             store_vec<T, VEC>(o, yrow + c);
           }
           if (c % hdim == 0) {
@@ -474,7 +541,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_gn_kernel(const T* 
                                                                        const T* b, const float* mean_in,
                                                                        const float* rstd_in, T* dattn, T* du,
                                                                        float* partial, int64_t rows, int heads, int hdim,
-                                                                       int concat) {
+                                                                       int concat, DropCtx dc) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = heads * hdim;
@@ -510,6 +577,19 @@ __global__ __launch_bounds__(kNormThreads) void norm_mul_bwd_gn_kernel(const T* 
       load_vec<T, VEC>(e2[k], dyrow + dim + c, ok && concat);     // d attn from the concat slot
       mean[k] = ok ? mean_in[row * heads + head[k]] : 0.f;
       rstd[k] = ok ? rstd_in[row * heads + head[k]] : 0.f;
+    }
+    if (dc.thr) {   // kernel-uniform: d y3 -> the gradients of the three slices before dropout (same masks, same scale)
+#pragma unroll
+      for (int k = 0; k < max_chunks<VEC>(); ++k) {
+        const int c = (k * 64 + lane) * VEC;
+        if (k < nch && c < dim) {
+          drop_apply<T, VEC>(gy[k], row * istride + (concat ? 2 * dim : 0) + c, dc);
+          if (concat) {
+            drop_apply<T, VEC>(e1[k], row * istride + c, dc);
+            drop_apply<T, VEC>(e2[k], row * istride + dim + c, dc);
+          }
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < max_chunks<VEC>(); ++k) {
@@ -635,7 +715,7 @@ static int ln_bwd(const void* dy, const void* x, const void* w, const float* mea
 
 template <typename T>
 static int nm_fwd(const void* attn, const void* u, const void* w, const void* b, void* y, float* mean, float* rstd,
-                  int64_t rows, int heads, int hdim, float eps, int gn, int concat, hipStream_t st) {
+                  int64_t rows, int heads, int hdim, float eps, int gn, int concat, DropCtx dc, hipStream_t st) {
   const int dim = heads * hdim;
   int v = vec_for<T>(dim, attn, u, y);
   if (v != 1 && !gn) v = vec_for<T>(dim, w, b, nullptr);
@@ -643,10 +723,10 @@ static int nm_fwd(const void* attn, const void* u, const void* w, const void* b,
   if (int e = check_dim(dim, v, "norm_mul_fwd")) return e;
   if (gn && heads > 16) return set_error(HSTU_EUNSUPPORTED, "norm_mul: group norm supports at most 16 heads");
   const int nb = norm_blocks(rows);
-#define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_fwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, heads, hdim, eps, concat)
+#define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_fwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, heads, hdim, eps, concat, dc)
   constexpr int VV = sizeof(T) == 2 ? 8 : 4;
   if (gn && gn_fast_ok(hdim, v))
-    hipLaunchKernelGGL((norm_mul_fwd_gn_kernel<T, VV>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, heads, hdim, eps, concat);
+    hipLaunchKernelGGL((norm_mul_fwd_gn_kernel<T, VV>), dim3(nb), dim3(kNormThreads), 0, st, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, (T*)y, mean, rstd, rows, heads, hdim, eps, concat, dc);
   else if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
   else { if (gn) NM_LAUNCH(VV, true); else NM_LAUNCH(VV, false); }
 #undef NM_LAUNCH
@@ -656,7 +736,7 @@ static int nm_fwd(const void* attn, const void* u, const void* w, const void* b,
 template <typename T>
 static int nm_bwd(const void* dy, const void* attn, const void* u, const void* w, const void* b, const float* mean,
                   const float* rstd, void* dattn, void* du, float* dweight, float* dbias, float* partial, int64_t rows,
-                  int heads, int hdim, int gn, int concat, hipStream_t st) {
+                  int heads, int hdim, int gn, int concat, DropCtx dc, hipStream_t st) {
   const int dim = heads * hdim;
   int v = vec_for<T>(dim, attn, u, dy);
   if (v != 1) v = vec_for<T>(dim, dattn, du, nullptr);
@@ -667,10 +747,10 @@ static int nm_bwd(const void* dy, const void* attn, const void* u, const void* w
   const int nb = norm_blocks(rows);
   const int nch = (dim + 64 * v - 1) / (64 * v);
   const size_t lds = gn ? kNormWaves * 32 * sizeof(float) : (size_t)kNormWaves * nch * 64 * v * sizeof(float);
-#define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_bwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, mean, rstd, (T*)dattn, (T*)du, partial, rows, heads, hdim, concat)
+#define NM_LAUNCH(V, G) hipLaunchKernelGGL((norm_mul_bwd_kernel<T, V, G>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, mean, rstd, (T*)dattn, (T*)du, partial, rows, heads, hdim, concat, dc)
   constexpr int VV = sizeof(T) == 2 ? 8 : 4;
   if (gn && gn_fast_ok(hdim, v))
-    hipLaunchKernelGGL((norm_mul_bwd_gn_kernel<T, VV>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, mean, rstd, (T*)dattn, (T*)du, partial, rows, heads, hdim, concat);
+    hipLaunchKernelGGL((norm_mul_bwd_gn_kernel<T, VV>), dim3(nb), dim3(kNormThreads), lds, st, (const T*)dy, (const T*)attn, (const T*)u, (const T*)w, (const T*)b, mean, rstd, (T*)dattn, (T*)du, partial, rows, heads, hdim, concat, dc);
   else if (v == 1) { if (gn) NM_LAUNCH(1, true); else NM_LAUNCH(1, false); }
   else { if (gn) NM_LAUNCH(VV, true); else NM_LAUNCH(VV, false); }
 #undef NM_LAUNCH
@@ -819,21 +899,45 @@ int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight, const
                  ln_bwd<float>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, st));
 }
 
-int hstu_norm_mul_fwd(const void* attn, const void* u, const void* weight, const void* bias, void* y, float* mean,
-                      float* rstd, int64_t rows, int32_t heads, int32_t head_dim, float eps, int group_norm,
-                      int concat_ux, int dtype, void* stream) {
+static int drop_ratio_ok(float r, const char* who) {
+  if (!(r >= 0.f && r < 1.f)) return set_error(HSTU_EINVAL, "%s: dropout_ratio must be in [0, 1) (got %g)", who, (double)r);
+  return HSTU_OK;
+}
+
+int hstu_norm_mul_dropout_fwd(const void* attn, const void* u, const void* weight, const void* bias, void* y, float* mean,
+                              float* rstd, int64_t rows, int32_t heads, int32_t head_dim, float eps, int group_norm,
+                              int concat_ux, float dropout_ratio, uint64_t seed, int dtype, void* stream) {
+  if (int e = drop_ratio_ok(dropout_ratio, "norm_mul_dropout_fwd")) return e;
   if (rows == 0) return HSTU_OK;
   if (!attn || !u || !weight || !bias || !y) return set_error(HSTU_EINVAL, "norm_mul_fwd: NULL tensor");
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_DTYPE(dtype, nm_fwd<bf16_t>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, st),
-                 nm_fwd<f16_t>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, st),
-                 nm_fwd<float>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, st));
+  const DropCtx dc = make_drop_ctx(dropout_ratio, seed);
+  DISPATCH_DTYPE(dtype, nm_fwd<bf16_t>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, dc, st),
+                 nm_fwd<f16_t>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, dc, st),
+                 nm_fwd<float>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, dc, st));
+}
+
+int hstu_norm_mul_fwd(const void* attn, const void* u, const void* weight, const void* bias, void* y, float* mean,
+                      float* rstd, int64_t rows, int32_t heads, int32_t head_dim, float eps, int group_norm,
+                      int concat_ux, int dtype, void* stream) {
+  return hstu_norm_mul_dropout_fwd(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux,
+                                   0.f, 0, dtype, stream);
 }
 
 int hstu_norm_mul_bwd(const void* dy, const void* attn, const void* u, const void* weight, const void* bias,
                       const float* mean, const float* rstd, void* dattn, void* du, float* dweight, float* dbias,
                       float* partial_ws, int64_t rows, int32_t heads, int32_t head_dim, int group_norm, int concat_ux,
                       int dtype, void* stream) {
+  return hstu_norm_mul_dropout_bwd(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads,
+                                   head_dim, group_norm, concat_ux, 0.f, 0, dtype, stream);
+}
+
+int hstu_norm_mul_dropout_bwd(const void* dy, const void* attn, const void* u, const void* weight, const void* bias,
+                              const float* mean, const float* rstd, void* dattn, void* du, float* dweight, float* dbias,
+                              float* partial_ws, int64_t rows, int32_t heads, int32_t head_dim, int group_norm,
+                              int concat_ux, float dropout_ratio, uint64_t seed, int dtype, void* stream) {
+  if (int e = drop_ratio_ok(dropout_ratio, "norm_mul_dropout_bwd")) return e;
+  const DropCtx dc = make_drop_ctx(dropout_ratio, seed);
   hipStream_t st = (hipStream_t)stream;
   const int width = group_norm ? heads : heads * head_dim;
   if (!dweight || !dbias) return set_error(HSTU_EINVAL, "norm_mul_bwd: dweight/dbias are required");
@@ -844,9 +948,9 @@ int hstu_norm_mul_bwd(const void* dy, const void* attn, const void* u, const voi
   }
   if (!dy || !attn || !u || !weight || !bias || !mean || !rstd || !dattn || !du || !partial_ws)
     return set_error(HSTU_EINVAL, "norm_mul_bwd: NULL tensor");
-  DISPATCH_DTYPE(dtype, nm_bwd<bf16_t>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, st),
-                 nm_bwd<f16_t>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, st),
-                 nm_bwd<float>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, st));
+  DISPATCH_DTYPE(dtype, nm_bwd<bf16_t>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, dc, st),
+                 nm_bwd<f16_t>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, dc, st),
+                 nm_bwd<float>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, dc, st));
 }
 
 int hstu_silu_fwd(const void* in, void* out, int64_t rows, int32_t cols, int64_t in_row_stride, int64_t out_row_stride,

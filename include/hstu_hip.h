@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 5
+#define HSTU_ABI_VERSION 6
 
 enum {
   HSTU_OK = 0,
@@ -224,8 +224,15 @@ size_t hstu_norm_bwd_workspace_bytes(int64_t rows, int32_t dim);
  * y = u * Norm(attn) with Norm = LayerNorm over the row or per-head GroupNorm,
  * optionally written as the concatenation [u, attn, y]  (rows, 3*dim).
  * Replaces _ln_mul_dropout_fwd/_bwd and _group_norm_mul_dropout_fwd/_bwd
- * (ops/triton/triton_hstu_linear.py:48-337,570-1036); dropout is not fused
- * (the reference's Philox stream is not reproducible).
+ * (ops/triton/triton_hstu_linear.py:48-337,570-1036).
+ *
+ * The _dropout_ entry points (ABI v6) fuse the reference's in-kernel dropout
+ * (triton_hstu_linear.py:101-120, 196-215; pt_hstu_linear.py:60-64 drops the concatenated
+ * tensor): every element of the (rows, dim | 3 dim) output is zeroed with probability
+ * p = round(dropout_ratio * 65536) / 65536 and the survivors are scaled by 1 / (1 - p).
+ * The mask is a pure function of (seed, element index): bwd -- and a forward recompute of y --
+ * regenerate it from the same seed, nothing is stored.  dropout_ratio == 0 is the plain op.
+ * bwd takes dy with respect to the DROPPED output.
  */
 int hstu_norm_mul_fwd(const void* attn, const void* u, const void* weight, const void* bias,
                       void* y, float* mean, float* rstd, int64_t rows, int32_t heads,
@@ -236,6 +243,17 @@ int hstu_norm_mul_bwd(const void* dy, const void* attn, const void* u, const voi
                       void* dattn, void* du, float* dweight, float* dbias, float* partial_ws,
                       int64_t rows, int32_t heads, int32_t head_dim, int group_norm,
                       int concat_ux, int dtype, void* stream);
+int hstu_norm_mul_dropout_fwd(const void* attn, const void* u, const void* weight,
+                              const void* bias, void* y, float* mean, float* rstd, int64_t rows,
+                              int32_t heads, int32_t head_dim, float eps, int group_norm,
+                              int concat_ux, float dropout_ratio, uint64_t seed, int dtype,
+                              void* stream);
+int hstu_norm_mul_dropout_bwd(const void* dy, const void* attn, const void* u, const void* weight,
+                              const void* bias, const float* mean, const float* rstd,
+                              void* dattn, void* du, float* dweight, float* dbias,
+                              float* partial_ws, int64_t rows, int32_t heads, int32_t head_dim,
+                              int group_norm, int concat_ux, float dropout_ratio, uint64_t seed,
+                              int dtype, void* stream);
 
 /* u = silu(u) in place on the leading `u_cols` columns of each row of a
  * (rows, row_stride) matrix, and its backward (du *= silu'(u_pre)); the SiLU-on-u

@@ -44,7 +44,7 @@ def test_ctypes_signature_table_covers_header():
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.hstu_abi_version() == 5
+    assert lib.hstu_abi_version() == _lib.ABI_VERSION == 6
     assert isinstance(lib.hstu_last_error(), bytes)
 
 
