@@ -29,6 +29,12 @@ constexpr int kFwdThreads = 256;
 #ifndef HSTU_FWD_MIN_WAVES
 #define HSTU_FWD_MIN_WAVES 2
 #endif
+#ifndef FWD_DMA_ASM
+#define FWD_DMA_ASM 1       // the planned DMA path issues its instruction through inline asm (see dma16_saddr_asm)
+#endif
+#ifndef FWD_DIAG_FAST
+#define FWD_DIAG_FAST 1     // plain causal, aligned tiles: the diagonal tile's mask through the S accumulator's start value
+#endif
 #ifndef FWD_DMA_FAST
 #define FWD_DMA_FAST 1      // K/V LDS-DMA source addresses: uniform base + 32-bit lane offset from a per-lane plan (3 VALU per chunk)
 #endif
@@ -36,7 +42,7 @@ constexpr int kFwdThreads = 256;
 #define FWD_EPI_FREE 1      // epilogue without a workgroup barrier: output tiles are parked in the ring slots that are dead after the last step
 #endif
 #ifndef FWD_EPI_SWAP
-#define FWD_EPI_SWAP 1      // parked output tile: 8-byte halves of a unit swapped on rows with bit 1 set (conflict-free ds_write_b64)
+#define FWD_EPI_SWAP 0      // parked output tile: 8-byte halves of a unit swapped on rows with bit 1 set (conflict-free ds_write_b64)
 #endif
 constexpr int kFwdRowsPerBlock = 128;
 
@@ -97,6 +103,22 @@ HSTU_DEV void tile_lds_write(const u32x4 (&reg)[NU], char* tile, int row0, int l
   }
 }
 
+// The DMA instruction itself goes through inline asm (M0 = LDS address of the 1 KiB chunk, 32-bit lane offset, 64-bit
+// scalar base).  Why: for the builtin, hipcc's waitcnt pass assumes that ANY later LDS read may alias the chunk in flight
+// and puts an `s_waitcnt vmcnt(0)` in front of it -- in the forward's loop that was the first transposed V read of every
+// key tile, i.e. each wave waited for the two tiles it had just requested before finishing the current one, and the
+// three-deep ring never had more than the current tile's latency of cover.  The asm form is invisible to that pass; the
+// kernel orders the consumers itself (counted vmcnt + barrier at the top of every tile).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+HSTU_DEV void dma16_saddr_asm(uint32_t off, const char* base, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_base) : "memory", "m0");
+}
+HSTU_DEV void dma16_vaddr_asm(const char* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // LDS-DMA variant (global_load_lds_dwordx4): wave `wave` of `nwaves` moves 1 KiB chunks of a
 // [32][D] tile from global memory straight into LDS -- no VGPRs, no ds_write, completion counted
 // by vmcnt (the compiler waits for it before the next __syncthreads()).  The hardware writes lane
@@ -117,39 +139,43 @@ HSTU_DEV void tile_dma(char* tile, const char* base, int64_t row_stride_bytes, i
     const int grow = min(row0 + row, len - 1);
     const int gunit = (unit * EPU < real_d) ? unit : 0;
     const char* g = base + (int64_t)grow * row_stride_bytes + gunit * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(tile + c * 1024), 16, 0, 0);
+    if (FWD_DMA_ASM) dma16_vaddr_asm(g, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile) + c * 1024);
+    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                          (__attribute__((address_space(3))) void*)(tile + c * 1024), 16, 0, 0);
   }
 }
 
 // The same with the lane-constant part of the address planned ahead (NI chunks per wave: c = wave + i nwaves): the lane's row
 // inside the tile and the byte offset of its (swizzled, clamped) unit.  A chunk then costs add + min + a 24-bit multiply-add,
 // and the load takes its 64-bit base from SGPRs (global_load_lds ... v_off32, s[base]).
-template <int NI> struct DmaPlan { int rl[NI]; uint32_t uo[NI]; };
+// Chunk i of a wave is chunk `wave + i nwaves`: with 4 waves and 16-unit rows that is 16 i rows further down, and the swizzle
+// only looks at the row modulo 16 -- the unit offset is the same for every chunk and the row advances by a constant, so the
+// plan is TWO registers per tensor (one set for K and V when their head dims agree).
+template <int NI> struct DmaPlan { int rl0; uint32_t uo0; int rstep; };
 
 template <typename T, int D, int NI>
 HSTU_DEV void dma_plan(DmaPlan<NI>& pl, int real_d, int wave, int nwaves, int lane) {
   constexpr int UPR = D * Elem<T>::kBytes / 16;
   constexpr int EPU = 16 / Elem<T>::kBytes;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int pidx = (wave + i * nwaves) * 64 + lane;
-    const int row = pidx / UPR, slot = pidx % UPR;
-    const int unit = slot ^ swz<UPR>(row);
-    pl.rl[i] = row;
-    pl.uo[i] = (unit * EPU < real_d) ? unit * 16 : 0;
-  }
+  const int pidx = wave * 64 + lane;
+  const int row = pidx / UPR, slot = pidx % UPR;
+  const int unit = slot ^ swz<UPR>(row);
+  pl.rl0 = row;
+  pl.uo0 = (unit * EPU < real_d) ? unit * 16 : 0;
+  pl.rstep = nwaves * 64 / UPR;
 }
 
 template <int NI>
 HSTU_DEV void tile_dma_fast(char* tile, const char* base, uint32_t row_stride_bytes, int row0, int len, const DmaPlan<NI>& pl,
                             int wave, int nwaves) {
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const uint32_t grow = (uint32_t)min(row0 + pl.rl[i], len - 1);
-    const uint32_t off = __umul24(grow, row_stride_bytes) + pl.uo[i];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                     (__attribute__((address_space(3))) void*)(tile + (wave + i * nwaves) * 1024), 16, 0, 0);
+    const uint32_t grow = (uint32_t)min(row0 + i * pl.rstep + pl.rl0, len - 1);
+    const uint32_t off = __umul24(grow, row_stride_bytes) + pl.uo0;
+    if (FWD_DMA_ASM) dma16_saddr_asm(off, base, lds0 + (wave + i * nwaves) * 1024);
+    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                          (__attribute__((address_space(3))) void*)(tile + (wave + i * nwaves) * 1024), 16, 0, 0);
   }
 }
 
@@ -322,6 +348,11 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 
+  // plain causal, rows aligned with the key tiles (no delta_q shift, no sliding-window start), |alpha| in the range where
+  // alpha * 1e30 neither overflows nor loses the mask: the diagonal tile's mask is a lane constant (mode 4 below)
+  const float aabs = fabsf(p.alpha);
+  const bool diag_fast = FWD_DIAG_FAST && !BIAS && mc.simple && i_shift == 0 && kv_lo == 0 && aabs > 1e-20f && aabs < 1e6f;
+
   // ---- K/V tiles stream through an NS-deep LDS ring filled by LDS-DMA: tiles t+1 .. t+NS-1 are in
   // flight while tile t is computed; one raw barrier per tile, loads are never drained in the loop
   // The source address of a chunk is (uniform tile base) + (row of the lane) x (row stride) + (swizzled unit) x 16.  Written
@@ -331,17 +362,20 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   // costs an add, a min and one 24-bit multiply-add into a 32-bit offset from the head's (scalar) base pointer.  Needs the
   // user's rows to span < 4 GiB and strides < 16 MiB (else the general path).
   constexpr int NIK = C::COUNTED ? C::NCH_K / 4 : 1, NIV = C::COUNTED ? C::NCH_V / 4 : 1;
-  const bool dma_fast = FWD_DMA_FAST && C::COUNTED && k_rs < (1 << 24) && v_rs < (1 << 24) &&
+  // (the two-register plan needs a wave's chunks to lie a multiple of 16 rows apart: 16-bit head dims 64 / 128, not fp32 rows)
+  constexpr bool plan_ok = (NIK == 1 || (4 * 64 / C::UPR_K) % 16 == 0) && (NIV == 1 || (4 * 64 / C::UPR_V) % 16 == 0);
+  const bool dma_fast = FWD_DMA_FAST && C::COUNTED && plan_ok && k_rs < (1 << 24) && v_rs < (1 << 24) &&
                         (int64_t)len * k_rs < (1LL << 32) && (int64_t)len * v_rs < (1LL << 32);   // workgroup-uniform
   DmaPlan<NIK> plk;
   DmaPlan<NIV> plv;
   if (dma_fast) {
     dma_plan<T, DQK, NIK>(plk, p.dqk, wave, 4, lane);
-    dma_plan<T, DV, NIV>(plv, p.dv, wave, 4, lane);
+    if (DQK == DV && p.dqk == p.dv) plv = DmaPlan<NIV>{plk.rl0, plk.uo0, plk.rstep};   // (the same registers)
+    else dma_plan<T, DV, NIV>(plv, p.dv, wave, 4, lane);
   }
-  auto issue_tile = [&](int t) {
+  auto issue_tile = [&](int t, int slot) {
     if (FWD_ABLATE & 4) return;   // (timing experiment: no K/V loads)
-    char* st = smem + (t % C::NS) * C::STAGE;
+    char* st = smem + slot * C::STAGE;
     if (dma_fast) {
       tile_dma_fast<NIK>(st, kbase, (uint32_t)k_rs, kv_lo + 32 * t, len, plk, wave, 4);
       tile_dma_fast<NIV>(st + C::KT, vbase, (uint32_t)v_rs, kv_lo + 32 * t, len, plv, wave, 4);
@@ -350,10 +384,13 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     tile_dma<T, DQK>(st, kbase, k_rs, kv_lo + 32 * t, len, p.dqk, wave, 4, lane);
     tile_dma<T, DV>(st + C::KT, vbase, v_rs, kv_lo + 32 * t, len, p.dv, wave, 4, lane);
   };
-  for (int t = 0; t < C::NS - 1 && t < ntiles; ++t) issue_tile(t);
+  for (int t = 0; t < C::NS - 1 && t < ntiles; ++t) issue_tile(t, t);
   HSTU_MARK(3);
 
+  // one key tile; `slot` = t % NS, as a compile-time constant in the unrolled loop (SLOT >= 0) or at run time
+  // (unrolling this loop by the ring depth -- ring slots as immediate LDS offsets -- triples the code and measured nothing)
   for (int t = 0; t < ntiles; ++t) {
+    const int slot = t % C::NS;
     const int j0 = kv_lo + (t << 5);
     // tile t has landed once at most (tiles issued after it) * PER_TILE DMA instructions are pending
     if constexpr (C::COUNTED) {
@@ -365,7 +402,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     }
     __builtin_amdgcn_s_barrier();   // every wave's chunks of tile t landed; stage (t-1) % NS is free
     asm volatile("" ::: "memory");
-    if (t + C::NS - 1 < ntiles) issue_tile(t + C::NS - 1);
+    if (t + C::NS - 1 < ntiles) issue_tile(t + C::NS - 1, (slot + C::NS - 1) % C::NS);
     HSTU_MARK(10);
     // (scalar work is not free: the general tile predicates cost ~100 SALU instructions per tile; plain-causal
     // batches -- no targets, window or contextual rows -- take two compares instead)
@@ -379,10 +416,17 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       tile_full = tile_act && mc.pair_fully_valid(i0w, 32, j0, 32);
     }
     if (wave_active && tile_act && !(FWD_ABLATE & 2)) {
-      const char* Kt = smem + (t % C::NS) * C::STAGE;
+      const char* Kt = smem + slot * C::STAGE;
       const char* Vt = Kt + C::KT;
       // ONE accumulator chain: back-to-back dependent MFMAs forward their result, and the VALU cycles a second chain
       // costs (16 adds per tile and lane) are what the long-sequence forward is bound by (N = 8192: +2..4 %)
+      // mode (wave-uniform): 0 no mask needed, 1 plain causal by compares, 2 general mask algebra, 3 targets / window by integer
+      // arithmetic, 4 plain causal with tile-aligned rows: the diagonal tile's mask is put into S itself
+      // (as hstu_attn_bwd_fold.cuh does through the accumulator's start value: a masked element is -1e30, alpha S is hugely negative, exp2 gives +inf,
+      // the sigmoid exactly 0 and P' = x * 0 = -0 -- the element-wise block needs no mask code; the predicate, key
+      // (r&3) + 8 (r>>2) + 4 hf <= query n32, is a compare against a lane constant).  Every other tile such a wave visits lies
+      // strictly below its rows: no mask at all (rows past the sequence end are zero-filled: silu(0) = 0).
+      const int mode = tile_full ? 0 : (mc.simple ? (diag_fast ? 4 : 1) : (mc.ctx == 0 ? 3 : 2));
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -391,9 +435,16 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         Frag a = lds_row_frag<T, C::UPR_K>(Kt, n32, hf * (DQK / 2) + kg * 8);
         s = E::mma(a, qf[kg], s);
       }
+      // (requesting the K fragments 2 / 3 / 4 / 8 ahead of the chain's MFMAs, or V fragments before the element-wise block:
+      // measured, no gain or a 4th register bank -- 169 registers cost a wave per SIMD and 22 %: docs/EXPERIMENTS.md)
+      if (mode == 4) {
+        const float neg = p.alpha < 0.f ? 1e30f : -1e30f;
+        const int x = n32 - 4 * hf;           // key (r&3) + 8 (r>>2) + 4 hf > query n32  <=>  (r&3) + 8 (r>>2) > x
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = ((r & 3) + 8 * (r >> 2) > x) ? neg : s[r];
+      }
       HSTU_MARK(11);
       Frag pb[2];
-      const int mode = tile_full ? 0 : (mc.simple ? 1 : (mc.ctx == 0 ? 3 : 2));   // wave-uniform
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {   // two halves keep only 8 fp32 temporaries live
         float pv[8];
@@ -430,10 +481,21 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
             if (head_loop) *LDS_PTR(u32x2, bslot) = w;
           }
         } else {
+          // two elements per instruction where the ISA has a packed fp32 form, and the exponent's argument straight from S
+          // (one multiply by -alpha log2 e instead of two): 4 VALU instructions per element, two of them transcendental
+          const f32x2 a2 = {p.alpha, p.alpha};
+          const f32x2 c2 = {-1.44269504088896340736f * p.alpha, -1.44269504088896340736f * p.alpha};
+          const f32x2 one2 = {1.f, 1.f};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float x = s[8 * h8 + j] * p.alpha;
-            pv[j] = x * fast_sigmoid(x);
+          for (int j = 0; j < 8; j += 2) {
+            const f32x2 sv = {s[8 * h8 + j], s[8 * h8 + j + 1]};
+            const f32x2 x = sv * a2, tt = sv * c2;
+            const f32x2 e = {__builtin_amdgcn_exp2f(tt[0]), __builtin_amdgcn_exp2f(tt[1])};
+            const f32x2 dn = e + one2;
+            const f32x2 sg = {__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])};
+            const f32x2 pr = x * sg;
+            pv[j] = pr[0];
+            pv[j + 1] = pr[1];
           }
         }
         if (mode == 1) {          // plain causal: key <= query, both in range

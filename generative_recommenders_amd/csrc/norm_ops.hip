@@ -75,7 +75,7 @@ HSTU_DEV float wave_sum(float x) {
 // One hash gives 32 bits = two 16-bit uniforms for the elements 2j and 2j+1: keep iff r16 >= thr, thr = round(p 65536),
 // survivors scaled by 65536 / (65536 - thr) (the exact inverse of the keep probability).  The hash is two rounds of
 // 32-bit multiply-xorshift finalisers (murmur3 fmix32, then lowbias32) with one seed word folded in before each;
-// oracle/hstu_oracle.py::dropout_keep_mask restates it bit for bit.
+// the CPU checker of the tests restates it bit for bit (dropout_keep_mask).
 struct DropCtx {
   uint32_t thr;        // 0 = no dropout
   float scale;

@@ -44,7 +44,8 @@ def test_ctypes_signature_table_covers_header():
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.hstu_abi_version() == _lib.ABI_VERSION == 6
+    from generative_recommenders_amd import _lib as L
+    assert lib.hstu_abi_version() == L.ABI_VERSION == 6
     assert isinstance(lib.hstu_last_error(), bytes)
 
 
