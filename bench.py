@@ -206,6 +206,57 @@ def attention_section(args, rank, world, device):
     )
 
 
+def rooflines(att, workload):
+    """roofline objects of one attention_section result.  Bound per workload: the jagged training shapes move ~64 FLOP per
+    byte, far under the ridge (~310): HBM.  C5 (delta-q microbatches against 8 K cached rows) re-reads K/V from L2 for every
+    query block and is bound by the matrix / vector pipes: its fraction is TFLOP/s of the causal FLOP model over the dense
+    bf16 MFMA peak."""
+    dom = "fwd" if att["fwd_only"] else "bwd"
+    if workload == "C5":
+        tf = att["tflops"]
+        main = {"bound": "mfma", "kernel": att["kernels"][dom], "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_bytes_per_launch": att[dom + "_bytes"],
+                "avg_launch_ms": att[dom + "_ms"],
+                "note": "VALU-limited in practice (two quarter-rate transcendentals per score); hbm-equivalent GB/s: %.0f" % att[dom + "_gbps"]}
+    else:
+        main = {"bound": "hbm", "kernel": att["kernels"][dom], "achieved": att[dom + "_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": att[dom + "_gbps"] / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": att[dom + "_bytes"],
+                "avg_launch_ms": att[dom + "_ms"]}
+    fwd = {"bound": main["bound"], "kernel": att["kernels"]["fwd"], "achieved": att["fwd_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": att["fwd_gbps"] / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": att["fwd_bytes"], "avg_launch_ms": att["fwd_ms"]}
+    if workload == "C5":
+        fwd = dict(main)
+    both = {"achieved": att["both_gbps"], "unit": "GB/s", "frac": att["both_gbps"] / HBM_PEAK_GBPS, "tflops_causal_model": att["tflops"]}
+    return main, fwd, both
+
+
+# the other shapes north_star names, run for a few steps after the headline so that the driver's record carries them
+EXTRA_WORKLOADS = [("M-jag", {}), ("M-full-d64", {"workload": "M-full", "head_dim": 64}), ("C2", {}), ("C3", {})]
+
+
+def extra_workloads(args, rank, world, device):
+    out = {}
+    for name, over in EXTRA_WORKLOADS:
+        a = argparse.Namespace(**vars(args))
+        a.workload = over.get("workload", name)
+        n, h, d, users, _ = WORKLOADS[a.workload]
+        a.max_seq_len, a.heads, a.head_dim, a.users_per_gpu = n, h, over.get("head_dim", d), users
+        a.steps, a.warmup = args.extra_steps, 3
+        a.sort_by_length = a.workload == "C3"
+        try:
+            att = attention_section(a, rank, world, device)
+            main, fwd, both = rooflines(att, a.workload)
+            out[name] = {"user_seqs_per_s": world * att["users"] * a.steps / att["elapsed"], "steps": a.steps,
+                         "users_per_gpu": a.users_per_gpu, "max_seq_len": n, "heads": h, "head_dim": a.head_dim,
+                         "fwd_ms": round(att["fwd_ms"], 4), "bwd_ms": round(att["bwd_ms"], 4), "bound": main["bound"],
+                         "frac_fwd": round(fwd["frac"], 4), "frac_bwd": round(main["frac"], 4), "frac_fwd_bwd": round(both["frac"], 4),
+                         "kernels": att["kernels"], "what": WORKLOADS[a.workload][4]}
+        except Exception as e:  # the headline number must survive a failure here
+            out[name] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+    return out
+
+
 def copy_bandwidth(device):
     n = 1 << 30
     a = torch.empty(n, dtype=torch.uint8, device=device)
@@ -262,14 +313,18 @@ def layer_section(args, rank, world, device):
     gy = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen)
     nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
 
-    def timed(recompute):
+    def timed(recompute, dropout):
         """recompute=True: the reference's STULayerConfig defaults (normed x, uvqk and y recomputed in the backward --
-        a memory saving sized for 80 GB parts); False: everything kept (3 layers x 1024 users: 2.4 GB of 288)."""
+        a memory saving sized for 80 GB parts); False: everything kept (3 layers x 1024 users: 2.4 GB of 288).
+        dropout: output_dropout_ratio of the layers (DLRM-v3 trains with hstu_linear_dropout_rate = 0.1,
+        dlrm_v3/configs.py:39), fused into the norm kernel, mask regenerated in backward."""
         torch.manual_seed(7)
         stack = STUStack([STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=d, attention_dim=d,
-                                                  output_dropout_ratio=0.0, use_group_norm=True, recompute_normed_x=recompute,
+                                                  output_dropout_ratio=dropout, use_group_norm=True, recompute_normed_x=recompute,
                                                   recompute_uvqk=recompute, recompute_y=recompute)) for _ in range(3)]).to(device)
-        reducer = dp.GradientAllReducer(stack.parameters())
+        stack.train()
+        # one bucket per layer, its all-reduce launched from inside backward when the layer's last gradient is in
+        reducer = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in stack._stu_layers], overlap=True)
 
         def step():
             for p in stack.parameters():
@@ -292,12 +347,19 @@ def layer_section(args, rank, world, device):
             dist.barrier()
         return dp.max_over_ranks(time.perf_counter() - t0, device), stack
 
-    elapsed_keep, _ = timed(False)
-    elapsed, stack = timed(True)
+    p_drop = args.layer_dropout
+    elapsed_keep, _ = timed(False, p_drop)
+    elapsed_nodrop, _ = timed(True, 0.0)
+    elapsed, stack = timed(True, p_drop)
     nparams = sum(p.numel() for p in stack.parameters())
     gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
     return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,
                 user_seqs_per_s=world * B * args.layer_steps / elapsed, params=nparams,
+                config=f"3 STU layers D=512, 4 heads of 128, group norm, targets; training mode, output_dropout_ratio={p_drop} "
+                       f"(fused, mask regenerated in backward), recompute normed_x / uvqk / y in backward; gradient all-reduce: "
+                       f"one bucket per layer launched from backward hooks",
+                dropout_off=dict(ms_per_step=elapsed_nodrop / args.layer_steps * 1e3,
+                                 user_seqs_per_s=world * B * args.layer_steps / elapsed_nodrop),
                 allreduce_bytes=nparams * 4,
                 no_recompute=dict(ms_per_step=elapsed_keep / args.layer_steps * 1e3,
                                   user_seqs_per_s=world * B * args.layer_steps / elapsed_keep),
@@ -498,12 +560,23 @@ def run(args):
 
     from generative_recommenders_amd import _lib
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HSTU ops are HIP kernels with no CPU fallback")
+    # The CPU baselines (10 + 8 s of host work on rank 0) run BEFORE the process group exists: the other ranks wait in the
+    # rendezvous of init_process_group (a store wait), not inside a collective under the RCCL watchdog.
+    cpu_res = None
+    if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu:
+        try:
+            cpu_res = cpu_baseline(args)
+        except Exception as e:  # pragma: no cover
+            cpu_res = {"error": repr(e)[:300]}
+        torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
     rank, local_rank, world = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HSTU ops are HIP kernels with no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()     # (== local_rank on a node with one GPU per rank)
+    # one device per rank (init_from_env refuses anything else under RCCL); the modulo only serves the gloo rehearsal of the
+    # multi-rank flow on a one-GPU box (HSTU_DIST_BACKEND=gloo)
+    dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     _lib.lib()
@@ -532,20 +605,13 @@ def run(args):
         },
         "device_ms_per_step": att["device_ms_per_step"], "step_spread": att["step_spread"],
     }
-    dom = "fwd" if att["fwd_only"] else "bwd"
-    res["roofline"] = {
-        "bound": "hbm", "kernel": att["kernels"][dom],
-        "achieved": att[dom + "_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att[dom + "_gbps"] / HBM_PEAK_GBPS,
-        "traffic": None, "algorithmic_bytes_per_launch": att[dom + "_bytes"], "avg_launch_ms": att[dom + "_ms"],
-    }
-    res["roofline_fwd"] = {
-        "bound": "hbm", "kernel": att["kernels"]["fwd"], "achieved": att["fwd_gbps"],
-        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": att["fwd_gbps"] / HBM_PEAK_GBPS,
-        "algorithmic_bytes_per_launch": att["fwd_bytes"], "avg_launch_ms": att["fwd_ms"],
-    }
-    res["roofline_fwd_bwd"] = {"achieved": att["both_gbps"], "unit": "GB/s", "frac": att["both_gbps"] / HBM_PEAK_GBPS,
-                               "tflops_causal_model": att["tflops"]}
+    res["roofline"], res["roofline_fwd"], res["roofline_fwd_bwd"] = rooflines(att, args.workload)
+    res["parity_at_this_size"] = ("by invariance only: batch-composition bit-exactness, delta == tail of full, linearity in V "
+                                  "(tests/test_attention_gpu.py); the reference-minted vectors at this head shape are "
+                                  "tests/golden/metric_shapes.npz (N = 200, 4 x 128)")
     attach_traffic(res, args, att)
+    if args.workload == "M-full" and not args.no_extra:
+        res["extra_workloads"] = extra_workloads(args, rank, world, device)
     if rank == 0:
         try:
             res["measured_copy_GBps"] = copy_bandwidth(device)
@@ -554,6 +620,7 @@ def run(args):
     if world > 1:
         try:
             res["rccl"] = rccl_section(world, device)
+            res["rccl"]["job"] = dp.describe_ranks(device)
         except Exception as e:  # pragma: no cover
             res["rccl"] = {"error": repr(e)[:300]}
     if not args.no_layer:
@@ -561,11 +628,8 @@ def run(args):
             res["layer"] = layer_section(args, rank, world, device)
         except Exception as e:  # the headline number must survive a failure of the secondary section
             res["layer"] = {"error": repr(e)[:300]}
-    if rank == 0 and not args.no_cpu:
-        try:
-            res["cpu_baseline"] = cpu_baseline(args)
-        except Exception as e:  # pragma: no cover
-            res["cpu_baseline"] = {"error": repr(e)[:300]}
+    if rank == 0 and cpu_res is not None:
+        res["cpu_baseline"] = cpu_res
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
@@ -598,6 +662,9 @@ def main():
     ap.add_argument("--head-dim", type=int, default=None)
     ap.add_argument("--layer-users-per-gpu", type=int, default=1024)
     ap.add_argument("--layer-steps", type=int, default=10)
+    ap.add_argument("--layer-dropout", type=float, default=0.1, help="output_dropout_ratio of the layer section (DLRM-v3: 0.1)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other workloads (extra_workloads)")
+    ap.add_argument("--extra-steps", type=int, default=8)
     ap.add_argument("--cpu-users", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--sort-by-length", type=int, default=None, help="1: heavy-first workgroup order (default: on for C3)")

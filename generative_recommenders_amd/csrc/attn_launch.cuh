@@ -11,15 +11,14 @@ static int launch_fwd_inst(const HstuAttnParams& p, hipStream_t st) {
   const int q_rows = p.delta_q > 0 ? p.delta_q : p.max_seq_len;
   const int nqb = (q_rows + kFwdRowsPerBlock - 1) / kFwdRowsPerBlock;
   auto kern = hstu_attn_fwd_kernel<T, DQK, DV, BIAS, false>;
-  const int tables = BIAS ? bias_table_bytes(p.max_seq_len, p.num_buckets) : 0;   // tables staged behind the ring
   // research-path bias, short sequences: one workgroup per (user, query block) walks the heads with the time buckets of
-  // its tile pairs as bytes in LDS (hstu_attn_fwd.cuh); the last query block keeps the most: 1 KiB per key tile and wave
-  const int tmax = (p.max_seq_len + 31) / 32;
-  int cache = 0;
-  for (int w = 0; w < kFwdRowsPerBlock / 32; ++w)
-    if (4 * (nqb - 1) + w < tmax) cache += (4 * (nqb - 1) + w + 1) * 1024;
-  const bool head_loop = BIAS && sizeof(T) == 2 && p.heads > 1 && p.delta_q == 0 && tmax <= 7 && p.ts_w && p.timestamps && p.num_buckets <= 255 &&
-                         p.contextual_seq_len == 0 && C::SMEM + tables + cache <= 52 * 1024 && attn_bias_head_loop_enabled();
+  // its tile pairs as bytes in LDS (hstu_attn_fwd.cuh); the decision is attn_misc.hip's (shared with attn_kernel_name)
+  int tables = 0, cache = 0;
+  if (attn_fwd_ring_bytes((int)sizeof(T), DQK, DV) != C::SMEM)
+    return set_error(HSTU_ELAUNCH, "hstu_attn_fwd: attn_fwd_ring_bytes is out of step with FwdCfg (%d vs %d)", attn_fwd_ring_bytes((int)sizeof(T), DQK, DV), C::SMEM);
+  const bool hl_ok = attn_fwd_head_loop_applicable(p, C::SMEM, &tables, &cache);   // (also fills tables / cache)
+  const bool head_loop = BIAS && sizeof(T) == 2 && hl_ok;
+  if (!BIAS) tables = 0;
   const int groups = ((head_loop ? p.batch : p.batch * p.heads) + 7) / 8;
   if constexpr (BIAS && sizeof(T) == 2) {   // (fp32 I/O: the plain kernel; its head-loop variant spills at 128 x 128)
     if (head_loop) kern = hstu_attn_fwd_kernel<T, DQK, DV, true, true>;

@@ -47,6 +47,28 @@ bool attn_bwd_quad_applicable(const HstuAttnBwdParams& bp) {
   return enabled && attn_bwd_fold_applicable(bp) && bp.fwd.dqk == 64;
 }
 
+// K/V ring of the forward kernel (FwdCfg in hstu_attn_fwd.cuh): three stages when every wave issues whole DMA instructions
+// per tile and a stage is at most 16 KiB, else two
+int attn_fwd_ring_bytes(int eb, int a, int v) {
+  const int stage = 32 * (a + v) * eb;
+  const int nch_k = 32 * (a * eb / 16) / 64, nch_v = 32 * (v * eb / 16) / 64;
+  const bool counted = nch_k % 4 == 0 && nch_v % 4 == 0;
+  return ((counted && stage <= 16384) ? 3 : 2) * stage;
+}
+
+bool attn_fwd_head_loop_applicable(const HstuAttnParams& p, int ring_bytes, int* tables_out, int* cache_out) {
+  const int q_rows = p.delta_q > 0 ? p.delta_q : p.max_seq_len;
+  const int nqb = (q_rows + 127) / 128, tmax = (p.max_seq_len + 31) / 32;
+  const int tables = p.pos_w ? bias_table_bytes(p.max_seq_len, p.num_buckets) : 0;
+  int cache = 0;      // the last query block keeps the most: 1 KiB per key tile and wave
+  for (int w = 0; w < 4; ++w)
+    if (4 * (nqb - 1) + w < tmax) cache += (4 * (nqb - 1) + w + 1) * 1024;
+  if (tables_out) *tables_out = tables;
+  if (cache_out) *cache_out = cache;
+  return p.pos_w && p.dtype != HSTU_DTYPE_F32 && p.heads > 1 && p.delta_q == 0 && tmax <= 7 && p.ts_w && p.timestamps &&
+         p.num_buckets <= 255 && p.contextual_seq_len == 0 && ring_bytes + tables + cache <= 52 * 1024 && attn_bias_head_loop_enabled();
+}
+
 // Name of the instantiation attn_launch.cuh / attn_fold.cuh dispatch (the same decisions, restated once here; the
 // launch tests compare it with the kernel names rocprofv3 reports).
 int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char* buf, size_t len) {
@@ -59,6 +81,8 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   else if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
   else if (bwd && attn_bwd_fold_bias_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_bias_kernel<%s,64>", dt);
+  else if (!bwd && attn_fwd_head_loop_applicable(p, attn_fwd_ring_bytes(p.dtype == HSTU_DTYPE_F32 ? 4 : 2, a, v), nullptr, nullptr))
+    snprintf(buf, len, "hstu_attn_fwd_kernel<%s,%d,%d,bias,heads>", dt, a, v);
   else snprintf(buf, len, "hstu_attn_%s_kernel<%s,%d,%d%s>", bwd ? "bwd" : "fwd", dt, a, v, p.pos_w ? ",bias" : "");
   return HSTU_OK;
 }

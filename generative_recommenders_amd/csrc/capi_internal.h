@@ -43,6 +43,11 @@ int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int ex
 // LDS bytes of the research-path bias state of a backward workgroup (histograms with *ts_copies privatised copies of
 // the time-bucket histogram + the staged tables) and the number of copies chosen; 0 without bias
 bool attn_bias_head_loop_enabled();
+// research-path forward, short sequences: does one workgroup per (user, query block) walk the heads (hstu_attn_fwd.cuh,
+// HEADS instantiation)?  ONE decision for the launcher and for attn_kernel_name.  `ring_bytes` = the K/V ring of the
+// instantiation (FwdCfg::SMEM); *tables / *cache = LDS bytes of the staged tables and of the bucket bytes.
+bool attn_fwd_head_loop_applicable(const HstuAttnParams& p, int ring_bytes, int* tables, int* cache);
+int attn_fwd_ring_bytes(int elem_bytes, int dqk_padded, int dv_padded);   // == FwdCfg<T, DQK, DV>::SMEM (checked by the launcher)
 bool attn_bwd_fold_bias_lds(const HstuAttnParams& p, int base, int* ts_copies, int* hist_bytes, int* smem);
 bool attn_bwd_fold_bias_applicable(const HstuAttnBwdParams& bp);
 int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies);

@@ -42,6 +42,9 @@
 #define FOLD_ABLATE 0      // timing experiments only (WRONG results; tools/ab_bwd.py): 1 no dQ stores, 2 no dk/dv
 #endif                     // stores, 4 no stage DMA after step 0, 8 no tail, 16 no K/V DMA, 32 no dQ GEMM, 64 no pairs,
                            // 128 / 256 every problem aliases one of the first 256 / 32 (Infinity-Cache / L2 resident data)
+#ifndef FOLD_DMA_FAST
+#define FOLD_DMA_FAST 1    // LDS-DMA source addresses as scalar base + 32-bit lane offset (3 instead of ~20 VALU per chunk)
+#endif
 #ifndef FOLD_PERSIST
 #define FOLD_PERSIST 2     // 0: one workgroup per (user, head); 1: one workgroup per CU walks the problems; 2: and issues the
 #endif                     // next problem's K/V tiles of the slots its own tail does not use
@@ -72,8 +75,14 @@ HSTU_DEV void dma16_asm(const char* g, uint32_t lds_base) {
 }
 #pragma clang diagnostic pop
 
+// Source address of a lane's 16 bytes: (scalar tile base) + 32-bit offset = row x stride + swizzled unit x 16 -- one min, one
+// 24-bit multiply-add per chunk and the 64-bit base from SGPRs, instead of a 64-bit multiply-add chain of ~20 VALU
+// instructions (hstu_attn_fwd.cuh, tile_dma_fast).  `fast` (workgroup-uniform): strides < 16 MiB and the user's rows within
+// 4 GiB of the base; otherwise 64-bit addresses.
+HSTU_DEV void dma16_saddr(uint32_t off, const char* base, uint32_t lds_base) { dma16_saddr_asm(off, base, lds_base); }
+
 template <typename T, int D>
-HSTU_DEV void fold_tile_dma(char* tile, const char* base, int64_t row_stride_bytes, int row0, int len, int wave, int lane) {
+HSTU_DEV void fold_tile_dma(char* tile, const char* base, int64_t row_stride_bytes, int row0, int len, int wave, int lane, bool fast = false) {
   constexpr int UPR = D * Elem<T>::kBytes / 16;
   constexpr int NCH = 32 * UPR / 64;   // 1 KiB chunks per tile
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile);
@@ -82,7 +91,8 @@ HSTU_DEV void fold_tile_dma(char* tile, const char* base, int64_t row_stride_byt
     const int row = pidx / UPR, slot = pidx % UPR;
     const int unit = slot ^ swz<UPR>(row);
     const int grow = min(row0 + row, len - 1);
-    dma16_asm(base + (int64_t)grow * row_stride_bytes + unit * 16, lds0 + c * 1024);
+    if (fast) dma16_saddr(__umul24((uint32_t)grow, (uint32_t)row_stride_bytes) + unit * 16, base, lds0 + c * 1024);
+    else dma16_asm(base + (int64_t)grow * row_stride_bytes + unit * 16, lds0 + c * 1024);
   }
 }
 
@@ -556,20 +566,25 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
   const int64_t q_rs = p.q_row_stride * C::EB, k_rs = p.k_row_stride * C::EB, v_rs = p.v_row_stride * C::EB,
                 do_rs = bp.do_row_stride * C::EB;
 
+  // (32-bit DMA offsets: see fold_tile_dma; the same test covers the next problem's K/V rows issued from this one's tail)
+  const int len_max = 32 * tmax;
+  const bool dma_fast = FOLD_DMA_FAST && q_rs < (1 << 24) && k_rs < (1 << 24) && v_rs < (1 << 24) && do_rs < (1 << 24) &&
+                        (int64_t)len_max * q_rs < (1LL << 32) && (int64_t)len_max * k_rs < (1LL << 32) &&
+                        (int64_t)len_max * v_rs < (1LL << 32) && (int64_t)len_max * do_rs < (1LL << 32);
   auto stage_dma = [&](int qa, int qb, bool b_on) {
-    fold_tile_dma<T, DQK>(stageA, qbase, q_rs, 32 * qa, len, wave, lane);
-    fold_tile_dma<T, DV>(stageA + C::KT, dobase, do_rs, 32 * qa, len, wave, lane);
+    fold_tile_dma<T, DQK>(stageA, qbase, q_rs, 32 * qa, len, wave, lane, dma_fast);
+    fold_tile_dma<T, DV>(stageA + C::KT, dobase, do_rs, 32 * qa, len, wave, lane, dma_fast);
     if (b_on) {
-      fold_tile_dma<T, DQK>(stageB, qbase, q_rs, 32 * qb, len, wave, lane);
-      fold_tile_dma<T, DV>(stageB + C::KT, dobase, do_rs, 32 * qb, len, wave, lane);
+      fold_tile_dma<T, DQK>(stageB, qbase, q_rs, 32 * qb, len, wave, lane, dma_fast);
+      fold_tile_dma<T, DV>(stageB + C::KT, dobase, do_rs, 32 * qb, len, wave, lane, dma_fast);
     }
   };
 
   // ---- prologue: the whole K/V block and the first two query tiles, all by LDS-DMA
   for (int t = 0; t < ((FOLD_ABLATE & 16) ? 0 : min(nt, pre_in)); ++t) {
     char* dst = smem + t * C::PAIR;
-    fold_tile_dma<T, DQK>(dst, kbase, k_rs, 32 * t, len, wave, lane);
-    fold_tile_dma<T, DV>(dst + C::KT, vbase, v_rs, 32 * t, len, wave, lane);
+    fold_tile_dma<T, DQK>(dst, kbase, k_rs, 32 * t, len, wave, lane, dma_fast);
+    fold_tile_dma<T, DV>(dst + C::KT, vbase, v_rs, 32 * t, len, wave, lane, dma_fast);
   }
   stage_dma(nt - 1, 0, 0 < nt - 1);
   for (int i = tid; i < kBwdWaves * F::DSB / 16; i += kBwdThreads) *LDS_PTR(u32x4, dsbuf + 16 * i) = u32x4{0u, 0u, 0u, 0u};
@@ -690,8 +705,8 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
     const int nt3 = (len3 + 31) >> 5;
     for (int t = a_last + 1; t < nt3; ++t) {
       char* dst = smem + t * C::PAIR;
-      fold_tile_dma<T, DQK>(dst, kb3, k_rs, 32 * t, len3, wave, lane);
-      fold_tile_dma<T, DV>(dst + C::KT, vb3, v_rs, 32 * t, len3, wave, lane);
+      fold_tile_dma<T, DQK>(dst, kb3, k_rs, 32 * t, len3, wave, lane, dma_fast);
+      fold_tile_dma<T, DV>(dst + C::KT, vb3, v_rs, 32 * t, len3, wave, lane, dma_fast);
     }
     pre_lo = a_last + 1;
   }

@@ -40,7 +40,7 @@ struct QuadCfg {
 };
 
 template <typename T, int D>
-HSTU_DEV void quad_tile_dma(char* tile, const char* base, int64_t row_stride_bytes, int row0, int len, int wave, int lane) {
+HSTU_DEV void quad_tile_dma(char* tile, const char* base, int64_t row_stride_bytes, int row0, int len, int wave, int lane, bool fast = false) {
   constexpr int UPR = D * Elem<T>::kBytes / 16;
   constexpr int NCH = 32 * UPR / 64;   // 1 KiB chunks per tile
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tile);
@@ -49,7 +49,8 @@ HSTU_DEV void quad_tile_dma(char* tile, const char* base, int64_t row_stride_byt
     const int row = pidx / UPR, slot = pidx % UPR;
     const int unit = slot ^ swz<UPR>(row);
     const int grow = min(row0 + row, len - 1);
-    dma16_asm(base + (int64_t)grow * row_stride_bytes + unit * 16, lds0 + c * 1024);
+    if (fast) dma16_saddr(__umul24((uint32_t)grow, (uint32_t)row_stride_bytes) + unit * 16, base, lds0 + c * 1024);   // (fold_tile_dma)
+    else dma16_asm(base + (int64_t)grow * row_stride_bytes + unit * 16, lds0 + c * 1024);
   }
 }
 
@@ -162,15 +163,19 @@ HSTU_DEV void quad_problem(const HstuAttnBwdParams& bp, int tmax, int uh, char* 
   const int64_t q_rs = p.q_row_stride * C::EB, k_rs = p.k_row_stride * C::EB, v_rs = p.v_row_stride * C::EB,
                 do_rs = bp.do_row_stride * C::EB;
 
+  const int len_max = 32 * tmax;
+  const bool dma_fast = FOLD_DMA_FAST && q_rs < (1 << 24) && k_rs < (1 << 24) && v_rs < (1 << 24) && do_rs < (1 << 24) &&
+                        (int64_t)len_max * q_rs < (1LL << 32) && (int64_t)len_max * k_rs < (1LL << 32) &&
+                        (int64_t)len_max * v_rs < (1LL << 32) && (int64_t)len_max * do_rs < (1LL << 32);
   auto stage_dma = [&](int qt) {
-    quad_tile_dma<T, D>(stage, qbase, q_rs, 32 * qt, len, wave, lane);
-    quad_tile_dma<T, D>(stage + C::KT, dobase, do_rs, 32 * qt, len, wave, lane);
+    quad_tile_dma<T, D>(stage, qbase, q_rs, 32 * qt, len, wave, lane, dma_fast);
+    quad_tile_dma<T, D>(stage + C::KT, dobase, do_rs, 32 * qt, len, wave, lane, dma_fast);
   };
   // ---- prologue: the whole K/V block and the first query tile, all by LDS-DMA
   for (int t = 0; t < ((QUAD_ABLATE & 16) ? 0 : nt); ++t) {
     char* dst = smem + t * C::PAIR;
-    quad_tile_dma<T, D>(dst, kbase, k_rs, 32 * t, len, wave, lane);
-    quad_tile_dma<T, D>(dst + C::KT, vbase, v_rs, 32 * t, len, wave, lane);
+    quad_tile_dma<T, D>(dst, kbase, k_rs, 32 * t, len, wave, lane, dma_fast);
+    quad_tile_dma<T, D>(dst + C::KT, vbase, v_rs, 32 * t, len, wave, lane, dma_fast);
   }
   stage_dma(nt - 1);
   for (int i = tid; i < Q::kMaxTiles * Q::DSB / 16; i += kQuadThreads) *LDS_PTR(u32x4, dsbuf + 16 * i) = u32x4{0u, 0u, 0u, 0u};

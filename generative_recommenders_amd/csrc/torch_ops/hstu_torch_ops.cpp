@@ -76,9 +76,18 @@ static Jagged as_jagged(const Tensor& q, const Tensor& k, const Tensor& v, const
   return j;
 }
 
+// The parameter structs cross into libhstu_hip.so by pointer: a core library of another ABI version would read other
+// fields at these offsets.  Checked once per process, on the first call that fills a struct.
+static void check_core_abi() {
+  static const int got = hstu_abi_version();
+  TORCH_CHECK(got == HSTU_ABI_VERSION, "libhstu_torch_ops.so was built against libhstu_hip ABI v", HSTU_ABI_VERSION,
+              " but the loaded libhstu_hip.so reports v", got, ": rebuild both (generative_recommenders_amd._lib.build())");
+}
+
 static void fill(HstuAttnParams& p, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& offsets, const OptT& num_targets,
                  Tensor& nt_keep, int64_t max_seq_len, double alpha, const OptT& attn_scale, Tensor& scale_keep,
                  int64_t max_attn_len, int64_t min_full, int64_t contextual) {
+  check_core_abi();
   memset(&p, 0, sizeof(p));
   p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr();
   p.seq_offsets = offsets.data_ptr();

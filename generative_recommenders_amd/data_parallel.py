@@ -12,7 +12,7 @@ collective at all; the layer benchmark calls ``GradientAllReducer.reduce()`` aft
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Tuple, Union
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.distributed as dist
@@ -33,9 +33,43 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             # ranks on one device; gloo moves the few control tensors through the host)
             backend = os.environ.get("HSTU_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            ndev = torch.cuda.device_count()
+            if local_rank >= ndev:
+                # two ranks on one device deadlock or fail inside RCCL at the first collective; say so here instead
+                raise RuntimeError(
+                    f"rank {rank} (LOCAL_RANK {local_rank}) has no GPU of its own: this node exposes {ndev} device(s) for "
+                    f"{world} ranks.  RCCL needs one device per rank; set HSTU_DIST_BACKEND=gloo to rehearse the "
+                    f"multi-rank flow on fewer GPUs.")
             torch.cuda.set_device(local_rank)      # RCCL binds a communicator to the device current at first use
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def describe_ranks(device: Union[torch.device, str] = "cpu") -> dict:
+    """Who is in the job: backend, library version and every rank's (host, device index, device name, PCI bus id),
+    gathered over the process group -- what NCCL_DEBUG=VERSION / INFO would print, as data for the bench line."""
+    import socket
+
+    me = {"rank": dist.get_rank() if dist.is_initialized() else 0, "host": socket.gethostname(), "pid": os.getpid()}
+    if torch.cuda.is_available() and str(device).startswith("cuda"):
+        i = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(i)
+        me.update(device=i, name=pr.name, bus_id=getattr(pr, "pci_bus_id", None), gcn_arch=getattr(pr, "gcnArchName", None))
+    info = {"backend": dist.get_backend() if dist.is_initialized() else None, "ranks": [me]}
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        allr: List[Optional[dict]] = [None] * dist.get_world_size()
+        dist.all_gather_object(allr, me)
+        info["ranks"] = allr
+    if info["backend"] == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # pragma: no cover
+            info["rccl_version"] = repr(e)
+        info["env"] = {k: os.environ[k] for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME", "RCCL_MSCCL_ENABLE")
+                       if k in os.environ}
+    devs = [(r.get("host"), r.get("device")) for r in info["ranks"] if r and "device" in r]
+    info["one_device_per_rank"] = len(set(devs)) == len(devs)
+    return info
 
 
 def shard_users(lengths: torch.Tensor, rank: int, world_size: int, balance: str = "count") -> torch.Tensor:
@@ -81,24 +115,98 @@ class GradientAllReducer:
     launch latency once.  Larger models split at ``bucket_bytes``.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True,
+                 buckets: Optional[Sequence[Iterable[torch.nn.Parameter]]] = None, overlap: bool = False):
+        """``buckets``: explicit parameter groups (e.g. one per layer) instead of the byte-size split of ``params``.
+        ``overlap``: launch a bucket's all-reduce from inside backward, as soon as its last gradient has been
+        accumulated (hooks); ``reduce()`` then only waits.  The reference's DDP does the same (train.py:269)."""
         self.average = average
         self.buckets: List[List[torch.nn.Parameter]] = []
-        cur: List[torch.nn.Parameter] = []
-        cur_bytes = 0
-        for p in self.params:
-            nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype):
+        if buckets is not None:
+            for grp in buckets:
+                cur = [p for p in grp if p.requires_grad]
+                if cur:
+                    self.buckets.append(cur)
+            self.params = [p for b in self.buckets for p in b]
+        else:
+            self.params = [p for p in params if p.requires_grad]
+            cur: List[torch.nn.Parameter] = []
+            cur_bytes = 0
+            for p in self.params:
+                nbytes = p.numel() * p.element_size()
+                if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype):
+                    self.buckets.append(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
                 self.buckets.append(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            self.buckets.append(cur)
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self.overlap = overlap
+        self._pending: List[int] = [0] * len(self.buckets)
+        self._work: List[Optional[object]] = [None] * len(self.buckets)
+        self._hooks = []
+        if overlap:
+            self._slot = {}
+            for bi, bucket in enumerate(self.buckets):
+                o = 0
+                for p in bucket:
+                    self._slot[id(p)] = (bi, o)
+                    o += p.numel()
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            self._reset()
+
+    # ---- overlapped mode: gradients land in the bucket's flat buffer as backward produces them; the bucket's collective
+    # starts when its last gradient is in (for a stack of layers: layer l's bucket reduces while layer l-1 runs backward)
+    def _reset(self) -> None:
+        self._pending = [len(b) for b in self.buckets]
+        self._work = [None] * len(self.buckets)
+
+    def _bucket_flat(self, bi: int, like: torch.Tensor) -> torch.Tensor:
+        n = sum(p.numel() for p in self.buckets[bi])
+        flat = self._flat[bi]
+        if flat is None or flat.numel() != n or flat.device != like.device or flat.dtype != like.dtype:
+            flat = torch.empty(n, dtype=like.dtype, device=like.device)
+            self._flat[bi] = flat
+        return flat
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        bi, o = self._slot[id(p)]
+        flat = self._bucket_flat(bi, p.grad)
+        view = flat[o : o + p.numel()].view_as(p)
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view          # the reduced values appear in p.grad without a copy back
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and dist.is_initialized() and dist.get_world_size() > 1:
+            self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def remove_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def reduce(self) -> None:
+        if self.overlap:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            for bi, work in enumerate(self._work):
+                if work is not None:
+                    work.wait()
+                    if self.average:
+                        self._flat[bi].div_(world)
+                elif world > 1 and self._pending[bi] != len(self.buckets[bi]):
+                    # some parameters of the bucket got no gradient this step: reduce what is there (zeros for the rest)
+                    flat = self._flat[bi]
+                    for p in self.buckets[bi]:
+                        if p.grad is None:
+                            b2, o = self._slot[id(p)]
+                            flat[o : o + p.numel()].zero_()
+                            p.grad = flat[o : o + p.numel()].view_as(p)
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                    if self.average:
+                        flat.div_(world)
+            self._reset()
+            return
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()

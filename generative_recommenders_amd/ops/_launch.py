@@ -73,13 +73,17 @@ _ORDER_CACHE = {}
 def length_order(seq_offsets: torch.Tensor) -> torch.Tensor:
     """users by descending length (int32 permutation) -- the launch order of the reference's ``sort_by_length``
     (ops/triton/triton_hstu_attention.py:1968-1973).  One argsort per batch: the layers of a stack call with the same
-    offsets tensor, so the last result is kept (keyed on the tensor's storage and version)."""
-    key = (seq_offsets.data_ptr(), seq_offsets._version, seq_offsets.numel(), seq_offsets.device)
+    offsets TENSOR OBJECT, so the last result is kept, keyed on that object (a weak reference: alive and the same
+    version).  Keying on the storage address would hand the next batch -- whose freshly built offsets the caching
+    allocator likes to put at the same address -- the previous batch's order: still a valid permutation, silently the
+    wrong one."""
+    import weakref
+
     hit = _ORDER_CACHE.get("last")
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    if hit is not None and hit[0]() is seq_offsets and hit[1] == seq_offsets._version:
+        return hit[2]
     order = torch.argsort(seq_offsets[1:] - seq_offsets[:-1], descending=True, stable=True).to(torch.int32)
-    _ORDER_CACHE["last"] = (key, order)
+    _ORDER_CACHE["last"] = (weakref.ref(seq_offsets), seq_offsets._version, order)
     return order
 
 
@@ -376,7 +380,9 @@ def layer_norm_bwd(dy, x, weight, mean, rstd):
     return dx, dw, db
 
 
-def norm_mul_fwd(attn, u, weight, bias, eps, num_heads, head_dim, group_norm, concat_ux):
+def norm_mul_fwd(attn, u, weight, bias, eps, num_heads, head_dim, group_norm, concat_ux, dropout_ratio=0.0, seed=0):
+    """``dropout_ratio > 0``: the fused output-stage dropout (hstu_norm_mul_dropout_fwd); the mask is a function of
+    (seed, element index) -- pass the same seed to norm_mul_bwd (and to a recompute of y)."""
     L.require_gpu_tensor(attn, "attn")
     attn, u = attn.contiguous(), u.contiguous()
     rows, dim = attn.shape
@@ -385,14 +391,16 @@ def norm_mul_fwd(attn, u, weight, bias, eps, num_heads, head_dim, group_norm, co
     mean, rstd = _f32(rows * ng, attn.device), _f32(rows * ng, attn.device)
     w, b = weight.to(attn.dtype).contiguous(), bias.to(attn.dtype).contiguous()
     with torch.cuda.device(attn.device):
-        L.check(L.lib().hstu_norm_mul_fwd(attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
-                                          mean.data_ptr(), rstd.data_ptr(), rows, num_heads, head_dim, float(eps),
-                                          int(group_norm), int(concat_ux), L.torch_dtype_code(attn.dtype),
-                                          L.current_stream_ptr(attn.device)))
+        L.check(L.lib().hstu_norm_mul_dropout_fwd(attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                                  mean.data_ptr(), rstd.data_ptr(), rows, num_heads, head_dim, float(eps),
+                                                  int(group_norm), int(concat_ux), float(dropout_ratio),
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, L.torch_dtype_code(attn.dtype),
+                                                  L.current_stream_ptr(attn.device)))
     return y, mean, rstd
 
 
-def norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, num_heads, head_dim, group_norm, concat_ux):
+def norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, num_heads, head_dim, group_norm, concat_ux, dropout_ratio=0.0,
+                 seed=0):
     dy, attn, u = dy.contiguous(), attn.contiguous(), u.contiguous()
     rows, dim = attn.shape
     dattn, du = torch.empty_like(attn), torch.empty_like(u)
@@ -401,11 +409,12 @@ def norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, num_heads, head_dim, gro
     ws = torch.empty(L.lib().hstu_norm_bwd_workspace_bytes(rows, dim), dtype=torch.uint8, device=attn.device)
     w, b = weight.to(attn.dtype).contiguous(), bias.to(attn.dtype).contiguous()
     with torch.cuda.device(attn.device):
-        L.check(L.lib().hstu_norm_mul_bwd(dy.data_ptr(), attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                          mean.data_ptr(), rstd.data_ptr(), dattn.data_ptr(), du.data_ptr(),
-                                          dw.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, num_heads, head_dim,
-                                          int(group_norm), int(concat_ux), L.torch_dtype_code(attn.dtype),
-                                          L.current_stream_ptr(attn.device)))
+        L.check(L.lib().hstu_norm_mul_dropout_bwd(dy.data_ptr(), attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                  mean.data_ptr(), rstd.data_ptr(), dattn.data_ptr(), du.data_ptr(),
+                                                  dw.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, num_heads, head_dim,
+                                                  int(group_norm), int(concat_ux), float(dropout_ratio),
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, L.torch_dtype_code(attn.dtype),
+                                                  L.current_stream_ptr(attn.device)))
     return dattn, du, dw, db
 
 

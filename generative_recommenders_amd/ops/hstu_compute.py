@@ -12,7 +12,6 @@ SURVEY.md App. F): results are identical whichever recompute flags are chosen.
 from typing import Optional, Tuple
 
 import torch
-import torch.nn.functional as F
 
 from generative_recommenders_amd.common import HammerKernel
 from generative_recommenders_amd.ops import _launch
@@ -59,22 +58,31 @@ class _SiluFunction(torch.autograd.Function):
         return _launch.silu_bwd(dy, x)
 
 
+def draw_dropout_seed() -> int:
+    """The seed of one fused-dropout call, drawn the way the reference draws it (triton_hstu_linear.py:376-377: torch's
+    default CPU generator, no device sync) -- ``torch.manual_seed`` makes a run reproducible."""
+    return int(torch.randint(low=0, high=2**62, size=(1,), dtype=torch.int64).item())
+
+
 class _NormMulFunction(torch.autograd.Function):
-    """y = u * Norm(attn) (optionally [u, attn, y]); unfused-GEMM variant used when dropout is on."""
+    """y = dropout(u * Norm(attn)) (optionally [u, attn, y]) as a node of its own, without the GEMM: the research layer's
+    output stage (its projection is an nn.Linear) and the tests' handle on the row kernels.  Dropout is fused exactly as in
+    _ComputeOutputFunction: the mask is regenerated from the seed in backward."""
 
     @staticmethod
-    def forward(ctx, attn, u, weight, bias, eps, num_heads, linear_dim, group_norm, concat_ux):
-        y, mean, rstd = _launch.norm_mul_fwd(attn, u, weight, bias, eps, num_heads, linear_dim, group_norm, concat_ux)
+    def forward(ctx, attn, u, weight, bias, eps, num_heads, linear_dim, group_norm, concat_ux, dropout_ratio=0.0, seed=0):
+        y, mean, rstd = _launch.norm_mul_fwd(attn, u, weight, bias, eps, num_heads, linear_dim, group_norm, concat_ux,
+                                             dropout_ratio, seed)
         ctx.save_for_backward(attn, u, weight, bias, mean, rstd)
-        ctx.meta = (num_heads, linear_dim, group_norm, concat_ux)
+        ctx.meta = (num_heads, linear_dim, group_norm, concat_ux, dropout_ratio, seed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         attn, u, weight, bias, mean, rstd = ctx.saved_tensors
-        H, Ld, gn, cat = ctx.meta
-        dattn, du, dw, db = _launch.norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, H, Ld, gn, cat)
-        return dattn, du, dw.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None
+        H, Ld, gn, cat, p_drop, seed = ctx.meta
+        dattn, du, dw, db = _launch.norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, H, Ld, gn, cat, p_drop, seed)
+        return dattn, du, dw.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None, None
 
 
 class _ComputeOutputFunction(torch.autograd.Function):
@@ -83,30 +91,34 @@ class _ComputeOutputFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, attn, u, x, norm_weight, norm_bias, output_weight, eps, num_heads, linear_dim, concat_ux,
-                group_norm, recompute_y):
+                group_norm, recompute_y, dropout_ratio=0.0, seed=0):
+        # dropout (training): inside the norm kernel, on all of [u, attn, u * Norm(attn)] as the reference's
+        # _ln_mul_dropout_fwd does (triton_hstu_linear.py:101-120); the mask is never stored -- the backward kernel and the
+        # recompute of y regenerate it from the seed
         y, mean, rstd = _launch.norm_mul_fwd(attn, u, norm_weight, norm_bias, eps, num_heads, linear_dim, group_norm,
-                                             concat_ux)
+                                             concat_ux, dropout_ratio, seed)
         out = torch.addmm(x, y, output_weight)
         saved = [attn, u, norm_weight, norm_bias, mean, rstd, output_weight]
         if not recompute_y:
             saved.append(y)
         ctx.save_for_backward(*saved)
-        ctx.meta = (eps, num_heads, linear_dim, concat_ux, group_norm, recompute_y)
+        ctx.meta = (eps, num_heads, linear_dim, concat_ux, group_norm, recompute_y, dropout_ratio, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        eps, H, Ld, cat, gn, recompute_y = ctx.meta
+        eps, H, Ld, cat, gn, recompute_y, p_drop, seed = ctx.meta
         attn, u, nw, nb, mean, rstd, Wo = ctx.saved_tensors[:7]
         if recompute_y:
-            y, _, _ = _launch.norm_mul_fwd(attn, u, nw, nb, eps, H, Ld, gn, cat)
+            y, _, _ = _launch.norm_mul_fwd(attn, u, nw, nb, eps, H, Ld, gn, cat, p_drop, seed)
         else:
             y = ctx.saved_tensors[7]
         dout = dout.contiguous()
         dy = torch.mm(dout, Wo.t())
         dWo = weight_grad_mm(y, dout)
-        dattn, du, dnw, dnb = _launch.norm_mul_bwd(dy, attn, u, nw, nb, mean, rstd, H, Ld, gn, cat)
-        return dattn, du, dout, dnw.to(nw.dtype), dnb.to(nb.dtype), dWo, None, None, None, None, None, None
+        dattn, du, dnw, dnb = _launch.norm_mul_bwd(dy, attn, u, nw, nb, mean, rstd, H, Ld, gn, cat, p_drop, seed)
+        return (dattn, du, dout, dnw.to(nw.dtype), dnb.to(nb.dtype), dWo, None, None, None, None, None, None, None,
+                None)
 
 
 def hstu_compute_output(
@@ -127,15 +139,11 @@ def hstu_compute_output(
     kernel: HammerKernel = HammerKernel.HIP,
 ) -> torch.Tensor:
     del kernel
-    if training and dropout_ratio > 0.0:
-        # Dropout sits between the norm kernel and the GEMM; torch's Philox stream is used
-        # (the reference's in-kernel tl.rand stream is not reproducible either: SURVEY.md §2b).
-        y = _NormMulFunction.apply(attn, u, norm_weight, norm_bias, norm_eps, num_heads, linear_dim, group_norm,
-                                   concat_ux)
-        y = F.dropout(y, p=dropout_ratio, training=True)
-        return torch.addmm(x, y, output_weight)
+    p_drop = float(dropout_ratio) if training else 0.0
+    torch._assert(0.0 <= p_drop < 1.0, "dropout_ratio must be in [0, 1)")
+    seed = draw_dropout_seed() if p_drop > 0.0 else 0
     return _ComputeOutputFunction.apply(attn, u, x, norm_weight, norm_bias, output_weight, norm_eps, num_heads,
-                                        linear_dim, concat_ux, group_norm, recompute_y_in_backward)
+                                        linear_dim, concat_ux, group_norm, recompute_y_in_backward, p_drop, seed)
 
 
 class _PreprocessAndAttentionFunction(torch.autograd.Function):

@@ -41,7 +41,11 @@ def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     S = 16 slabs (fewer for short inputs: a slab keeps >= 2048 rows), multiplied as one batched GEMM (S x as many tiles) with fp32 partial results, and summed."""
     L, K = x.shape
     N = dy.shape[1]
-    S = min(_SPLIT_SLABS, L // _MIN_SLAB_ROWS)
+    # slabs: 16 at the DLRM-v3 projection shapes (swept: profiles/r02_sweep_wgrad.json), fewer when the single GEMM already
+    # has an output tile per CU (wide projections: the split only adds a reduction) or when the fp32 partials
+    # (S x K x N x 4 bytes) would pass 64 MiB
+    tiles = -(-K // 256) * -(-N // 256)
+    S = min(_SPLIT_SLABS, L // _MIN_SLAB_ROWS, max(1, 256 // tiles), max(1, (64 << 20) // (K * N * 4)))
     if not x.is_cuda or S <= 1:
         return torch.mm(x.t(), dy)
     slab = (L // S) // 64 * 64

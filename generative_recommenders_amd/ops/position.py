@@ -24,12 +24,13 @@ _FN = {"sqrt": 0, "log": 1}
 TIME_BUCKET_CLAMP = os.environ.get("HSTU_TIME_BUCKET_CLAMP", "table")
 
 
-def _max_time_bucket(ts_w: torch.Tensor) -> int:
-    if TIME_BUCKET_CLAMP == "table":
+def _max_time_bucket(ts_w: torch.Tensor, clamp: Optional[str] = None) -> int:
+    clamp = clamp or TIME_BUCKET_CLAMP        # (module default: read at call time, so tests / callers may set it late)
+    if clamp == "table":
         return ts_w.shape[0] - 1
-    if TIME_BUCKET_CLAMP == "pytorch_path":
+    if clamp == "pytorch_path":
         return min(ts_w.shape[1] - 1, ts_w.shape[0] - 1)
-    raise RuntimeError(f"TIME_BUCKET_CLAMP must be 'table' or 'pytorch_path', got {TIME_BUCKET_CLAMP!r}")
+    raise RuntimeError(f"time_bucket_clamp must be 'table' or 'pytorch_path', got {clamp!r}")
 
 
 def _table_grad(g: torch.Tensor, idx: torch.Tensor, table_rows: int) -> torch.Tensor:
@@ -48,7 +49,7 @@ def _table_grad(g: torch.Tensor, idx: torch.Tensor, table_rows: int) -> torch.Te
 class _AddTsPosFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, alpha, x, seq_offsets, timestamps, num_targets, pos_w, ts_w, max_contextual_seq_len,
-                interleave_targets, time_bucket_fn):
+                interleave_targets, time_bucket_fn, time_bucket_clamp=None):
         for name, t in (("seq_embeddings", x), ("seq_offsets", seq_offsets), ("timestamps", timestamps),
                         ("position_embeddings_weight", pos_w), ("timestamp_embeddings_weight", ts_w)):
             L.require_gpu_tensor(t, name)
@@ -61,7 +62,7 @@ class _AddTsPosFunction(torch.autograd.Function):
         out = torch.empty_like(x)
         pos_idx = torch.empty(rows, dtype=torch.int32, device=x.device)
         ts_idx = torch.empty(rows, dtype=torch.int32, device=x.device)
-        max_bucket = _max_time_bucket(tw)
+        max_bucket = _max_time_bucket(tw, time_bucket_clamp)
         if rows:
             with torch.cuda.device(x.device):
                 L.check(L.lib().hstu_add_ts_pos_emb_fwd(
@@ -82,7 +83,7 @@ class _AddTsPosFunction(torch.autograd.Function):
         dx = g * alpha
         dpos = _table_grad(g, pos_idx, n_pos).to(pos_dtype) if ctx.needs_input_grad[5] else None
         dts = _table_grad(g, ts_idx, n_ts).to(ts_dtype) if ctx.needs_input_grad[6] else None
-        return None, dx, None, None, None, dpos, dts, None, None, None
+        return None, dx, None, None, None, dpos, dts, None, None, None, None
 
 
 def add_timestamp_positional_embeddings(
@@ -99,10 +100,15 @@ def add_timestamp_positional_embeddings(
     interleave_targets: bool,
     time_bucket_fn: str = "sqrt",
     kernel: HammerKernel = HammerKernel.HIP,
+    time_bucket_clamp: Optional[str] = None,
 ) -> torch.Tensor:
     """Same signature as the reference (``max_seq_len`` / ``seq_lengths`` are implied by ``seq_offsets`` and unused:
-    nothing is padded)."""
+    nothing is padded), plus ``time_bucket_clamp``: where the largest time bucket is clamped -- "table" (the last table
+    row: the reference's GPU path, triton_position.py:275,295), "pytorch_path" (min(D - 1, last row): its PyTorch branch,
+    pt_position.py:101), None = the module default TIME_BUCKET_CLAMP ("table" unless HSTU_TIME_BUCKET_CLAMP says
+    otherwise)."""
     del max_seq_len, seq_lengths, kernel
     assert time_bucket_fn in ["sqrt", "log"]
     return _AddTsPosFunction.apply(alpha, seq_embeddings, seq_offsets, timestamps, num_targets, position_embeddings_weight,
-                                   timestamp_embeddings_weight, max_contextual_seq_len, interleave_targets, time_bucket_fn)
+                                   timestamp_embeddings_weight, max_contextual_seq_len, interleave_targets, time_bucket_fn,
+                                   time_bucket_clamp)

@@ -242,17 +242,20 @@ class SequentialTransductionUnitJagged(torch.nn.Module):
 
     def _output_rows(self, u: torch.Tensor, attn: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         """o(dropout(u * LN(attn) | [u, LN(attn), u * LN(attn)])) + x for the rows given (hstu.py:426-444)"""
-        from generative_recommenders_amd.ops.hstu_compute import _NormMulFunction
+        from generative_recommenders_amd.ops.hstu_compute import _NormMulFunction, draw_dropout_seed
         from generative_recommenders_amd.ops.layer_norm import layer_norm
 
         H, Ld = self._num_heads, self._linear_dim
         w1 = torch.ones(Ld * H, dtype=x.dtype, device=x.device)
         if self._concat_ua:
             a = layer_norm(attn, w1, torch.zeros_like(w1), self._eps)
-            o_input = torch.cat([u, a, u * a], dim=-1)
+            o_input = F.dropout(torch.cat([u, a, u * a], dim=-1), p=self._dropout_ratio, training=self.training)
         else:
-            o_input = _NormMulFunction.apply(attn, u.contiguous(), w1, torch.zeros_like(w1), self._eps, H, Ld, False, False)
-        return self._o(F.dropout(o_input, p=self._dropout_ratio, training=self.training)) + x
+            # dropout inside the norm kernel (mask regenerated from the seed in backward: ops/hstu_compute.py)
+            p_drop = float(self._dropout_ratio) if self.training else 0.0
+            o_input = _NormMulFunction.apply(attn, u.contiguous(), w1, torch.zeros_like(w1), self._eps, H, Ld, False, False,
+                                             p_drop, draw_dropout_seed() if p_drop > 0.0 else 0)
+        return self._o(o_input) + x
 
     def forward(self, x: torch.Tensor, x_offsets: torch.Tensor, all_timestamps: Optional[torch.Tensor],
                 invalid_attn_mask: torch.Tensor, delta_x_offsets: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,

@@ -60,7 +60,11 @@ def test_layer_norm_golden_and_bwd():
 
 @pytest.mark.parametrize("rows,dim,dtype", [(0, 64, torch.float32), (1, 32, torch.float32), (1000, 512, torch.bfloat16),
                                             (777, 100, torch.float32), (300, 37, torch.bfloat16), (64, 1024, torch.float16),
-                                            (5000, 512, torch.float32)])
+                                            (5000, 512, torch.float32),
+                                            # rows wider than 1024 elements (the reference's kernel takes any D,
+                                            # triton_layer_norm.py:340): the wide instance of the row kernels, up to 4096
+                                            (200, 2048, torch.bfloat16), (65, 4096, torch.float32), (33, 1536, torch.float16),
+                                            (17, 1500, torch.float32)])
 def test_layer_norm_sweep(rows, dim, dtype):
     """N in [0, 10000], arbitrary D (ops/tests/layer_norm_test.py:62-80)."""
     from generative_recommenders_amd.ops.layer_norm import layer_norm
@@ -84,6 +88,54 @@ def test_layer_norm_sweep(rows, dim, dtype):
     wt = dict(rtol=1e-3, atol_scale=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol_scale=1e-2)
     _close(wd.grad, dw, what="dw", **wt)
     _close(bd.grad, db, what="db", **wt)
+
+
+@pytest.mark.parametrize("heads,hd,group_norm,dtype", [(16, 128, True, torch.bfloat16), (16, 128, False, torch.float32),
+                                                       (8, 512, True, torch.float32), (12, 100, False, torch.bfloat16)])
+def test_norm_mul_wide_rows(heads, hd, group_norm, dtype):
+    """H x hidden_dim = 1200 .. 4096 (HSTU-large: 16 heads of 128): y = [u, attn, u * Norm(attn)] and its backward against the
+    oracle.  Past 4096 elements per row the op says so."""
+    from generative_recommenders_amd.ops import _launch
+
+    rows, dim = 77, heads * hd
+    g = torch.Generator().manual_seed(dim)
+    attn = torch.randn(rows, dim, generator=g).to(dtype)
+    u = torch.randn(rows, dim, generator=g).to(dtype)
+    width = heads if group_norm else dim
+    w = (1 + 0.1 * torch.randn(width, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(width, generator=g)).to(dtype)
+    y, mean, rstd = _launch.norm_mul_fwd(attn.to(DEV), u.to(DEV), w.to(DEV), b.to(DEV), 1e-5, heads, hd, group_norm, True)
+    ref = O.norm_mul(attn.double().numpy(), u.double().numpy(), w.double().numpy(), b.double().numpy(), 1e-5, True, group_norm, heads, hd)
+    tol = dict(rtol=1e-3, atol_scale=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol_scale=4e-3)
+    _close(y, ref, what="wide norm_mul y", **tol)
+    # backward: against torch autograd on the same formula in fp64 on the CPU
+    a64, u64 = attn.double().requires_grad_(), u.double().requires_grad_()
+    w64, b64 = w.double().requires_grad_(), b.double().requires_grad_()
+    if group_norm:
+        xh = a64.view(rows, heads, hd)
+        n = (xh - xh.mean(-1, keepdim=True)) / torch.sqrt(xh.var(-1, unbiased=False, keepdim=True) + 1e-5)
+        n = (n * w64.view(1, heads, 1) + b64.view(1, heads, 1)).reshape(rows, dim)
+    else:
+        n = torch.nn.functional.layer_norm(a64, (dim,), w64, b64, 1e-5)
+    y64 = torch.cat([u64, a64, u64 * n], dim=1)
+    dy = torch.randn(rows, 3 * dim, generator=g).to(dtype)
+    y64.backward(dy.double())
+    dattn, du, dw, db = _launch.norm_mul_bwd(dy.to(DEV), attn.to(DEV), u.to(DEV), w.to(DEV), b.to(DEV), mean, rstd, heads, hd,
+                                             group_norm, True)
+    _close(dattn, a64.grad.numpy(), what="wide norm_mul dattn", **tol)
+    _close(du, u64.grad.numpy(), what="wide norm_mul du", **tol)
+    wt = dict(rtol=1e-3, atol_scale=1e-4)
+    assert dw.dtype == torch.float32
+    _close(dw, w64.grad.numpy(), what="wide norm_mul dw", **wt)
+    _close(db, b64.grad.numpy(), what="wide norm_mul db", **wt)
+
+
+def test_rows_past_4096_are_refused():
+    from generative_recommenders_amd.ops.layer_norm import layer_norm
+
+    x = torch.randn(4, 4104, device=DEV)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        layer_norm(x, torch.ones(4104, device=DEV), torch.zeros(4104, device=DEV), 1e-5)
 
 
 def test_uvqk_golden_fwd_bwd():

@@ -49,6 +49,63 @@ def test_gloo_world2_shard_and_allreduce(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def _worker_overlap(rank, world, port, out_dir):
+    """per-layer buckets reduced from inside backward (hooks) == the single-process gradient; two steps, with p.grad reset
+    to None in between as a training loop does"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from generative_recommenders_amd import data_parallel as dp
+
+    dp.init_from_env(backend="gloo")
+    mk = lambda: torch.nn.Sequential(*[torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh()) for _ in range(3)])
+    torch.manual_seed(0)
+    model = mk()
+    red = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in model], overlap=True, average=False)
+    assert len(red.buckets) == 3
+    lengths = torch.tensor([5, 1, 9, 3, 7, 2, 8, 4])
+    mine = dp.shard_users(lengths, rank, world)
+    g = torch.Generator().manual_seed(123)
+    torch.manual_seed(0)
+    ref = mk()
+    for step in range(2):
+        data = torch.randn(8, 8, generator=g)
+        for p in model.parameters():
+            p.grad = None
+        model(data[mine]).pow(2).sum().backward()      # the collectives start inside this call
+        red.reduce()
+        for p in ref.parameters():
+            p.grad = None
+        ref(data).pow(2).sum().backward()
+        for p, q in zip(model.parameters(), ref.parameters()):
+            torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+    info = dp.describe_ranks()
+    assert info["backend"] == "gloo" and [r["rank"] for r in info["ranks"]] == list(range(world))
+    dist.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_overlapped_per_layer_buckets(tmp_path):
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(_worker_overlap, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_nccl_refuses_more_ranks_than_devices(monkeypatch):
+    """two ranks on one GPU must fail loudly at start-up, not hang in the first collective"""
+    import pytest
+
+    from generative_recommenders_amd import data_parallel as dp
+
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(RuntimeError, match="no GPU of its own"):
+        dp.init_from_env(backend="nccl")
+
+
 def test_shard_users_partitions():
     from generative_recommenders_amd import data_parallel as dp
 

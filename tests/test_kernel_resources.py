@@ -67,6 +67,10 @@ def test_no_kernel_spills_or_uses_scratch():
     # The folded backward at 128 x 128 spills 2 registers since its dQ GEMM got exact slot counts per step (four more copies
     # of that phase): measured 1.4 % FASTER than the spill-free static-slot version on the same box (tools/ab_bwd.py).
     bounded = {"hstu_attn_bwd_fold_bias_kernel": 4, "hstu_attn_bwd_fold_kernelIDF16bLi128ELi128E": 2, "hstu_attn_bwd_fold_kernelIDF16_Li128ELi128E": 2, "hstu_attn_bwd_kernelIDF16bLi128ELi128ELb1E": 1, "hstu_attn_bwd_kernelIDF16_Li128ELi128ELb1E": 1}
+    # The WIDE instances of the row kernels (namespace nw4: rows of 1025 .. 4096 elements, csrc/norm_kernels.inc) hold four
+    # times the pieces per lane; their backward kernels spill.  They exist so that H x hidden_dim > 1024 works at all (the
+    # reference's kernels take any D); every BASELINE configuration (<= 1024) runs the narrow instances, which may not spill.
+    accepted = accepted + ("N4hstu3nw4",)
     bad = {k: v for k, v in ks.items() if (v["spill"] or v["scratch"]) and "hstu" in k and not any(a in k for a in accepted)
            and not any(b in k and v["spill"] <= n for b, n in bounded.items())}
     assert not bad, f"kernels with register spills / scratch: {bad}"
