@@ -32,6 +32,9 @@ constexpr int kFwdThreads = 256;
 #ifndef FWD_DMA_ASM
 #define FWD_DMA_ASM 1       // the planned DMA path issues its instruction through inline asm (see dma16_saddr_asm)
 #endif
+#ifndef FWD_DMA_FIRST
+#define FWD_DMA_FIRST 0     // the first K/V tiles are requested before the Q rows (prologue: one memory round trip instead of two)
+#endif
 #ifndef FWD_DIAG_FAST
 #define FWD_DIAG_FAST 1     // plain causal, aligned tiles: the diagonal tile's mask through the S accumulator's start value
 #endif
@@ -316,27 +319,26 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   int lane_h = lane_wg;
   if constexpr (head_loop) asm volatile("" : "+v"(lane_h));
   const int lane = lane_h, n32 = lane & 31, hf = lane >> 5;
-  // ---- Q fragment of this wave (B operand of S^T = K Q^T): lane (q = n32, hf) holds
-  // elements hf*DQK/2 + 8*kg .. +8 of its row: one contiguous half row per lane.
   Frag qf[C::KG];
-  {
-    const int ld_row = min(my_row, nq_rows - 1);   // clamped: always a valid row of this user
-    const char* qrow = (const char*)p.q + ((q_base + ld_row) * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
-    RawFrag<T> raw[C::KG];
-#pragma unroll
-    for (int kg = 0; kg < C::KG; ++kg) {
-      const int e0 = hf * (DQK / 2) + kg * 8;
-      raw[kg] = global_row_frag_issue<T>(qrow, e0 < p.dqk ? e0 : 0, e0 + 4 < p.dqk);
-    }
-#pragma unroll
-    for (int kg = 0; kg < C::KG; ++kg) {
-      const int e0 = hf * (DQK / 2) + kg * 8;
-      qf[kg] = finish_row_frag<T>(raw[kg], row_ok && e0 < p.dqk, e0 + 4 < p.dqk);
-    }
+#define HSTU_FWD_LOAD_Q()                                                                                                   \
+  {                                                                                                                          \
+    const int ld_row = min(my_row, nq_rows - 1); /* clamped: always a valid row of this user */                              \
+    const char* qrow = (const char*)p.q + ((q_base + ld_row) * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;     \
+    RawFrag<T> raw[C::KG];                                                                                                   \
+    _Pragma("unroll") for (int kg = 0; kg < C::KG; ++kg) {                                                                   \
+      const int e0 = hf * (DQK / 2) + kg * 8;                                                                                \
+      raw[kg] = global_row_frag_issue<T>(qrow, e0 < p.dqk ? e0 : 0, e0 + 4 < p.dqk);                                        \
+    }                                                                                                                        \
+    _Pragma("unroll") for (int kg = 0; kg < C::KG; ++kg) {                                                                   \
+      const int e0 = hf * (DQK / 2) + kg * 8;                                                                                \
+      qf[kg] = finish_row_frag<T>(raw[kg], row_ok && e0 < p.dqk, e0 + 4 < p.dqk);                                           \
+    }                                                                                                                        \
   }
-
-  // (issuing these Q loads, then the first K/V tiles, and only then waiting for the Q fragments -- the Q round trip under
-  // the DMA's instead of in front of it -- was measured: 1.391 -> 1.420 ms at head dim 128, no change at 64)
+  // ---- Q fragment of this wave (B operand of S^T = K Q^T): lane (q = n32, hf) holds elements hf*DQK/2 + 8*kg .. +8 of its
+  // row: one contiguous half row per lane.  FWD_DMA_FIRST (measured 1.6 % SLOWER, twice: off): the first K/V tiles requested BEFORE the Q rows -- VMEM
+  // operations complete in order, so the wait for the Q fragments then also covers the first tile, and the Q round trip
+  // (~1.3 K cycles in which the workgroup had nothing in flight) lies under the DMA's.
+  if (!FWD_DMA_FIRST) HSTU_FWD_LOAD_Q()
   HSTU_MARK(2);
   const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
   const char* vbase = (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * C::EB;
@@ -385,6 +387,8 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     tile_dma<T, DV>(st + C::KT, vbase, v_rs, kv_lo + 32 * t, len, p.dv, wave, 4, lane);
   };
   for (int t = 0; t < C::NS - 1 && t < ntiles; ++t) issue_tile(t, t);
+  if (FWD_DMA_FIRST) HSTU_FWD_LOAD_Q()
+#undef HSTU_FWD_LOAD_Q
   HSTU_MARK(3);
 
   // one key tile; `slot` = t % NS, as a compile-time constant in the unrolled loop (SLOT >= 0) or at run time

@@ -8,10 +8,10 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-layer --no-cpu $*"
+BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-layer --no-cpu --no-extra $*"
 # kernel trace of the SAME command the bench line comes from (default --steps 50 --warmup 10, attention section only)
 export PROF_WARMUP=10
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r -- python $ROOT/bench.py --no-layer --no-cpu $* > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r -- python $ROOT/bench.py --no-layer --no-cpu --no-extra $* > $OUT/stats.log 2>&1
 i=0
 for CTRS in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \

@@ -8,6 +8,6 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 export PROF_WARMUP=10
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r -- python $ROOT/bench.py --no-layer --no-cpu $* > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r -- python $ROOT/bench.py --no-layer --no-cpu --no-extra $* > $OUT/stats.log 2>&1
 python $ROOT/tools/prof_summary.py $OUT > $OUT/summary.md 2>&1
 find $OUT -name "*.db" -delete; find $OUT -type d -empty -delete; head -30 $OUT/summary.md

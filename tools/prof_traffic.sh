@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-layer --no-cpu $*"
+BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-layer --no-cpu --no-extra $*"
 i=0
 for CTRS in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
