@@ -569,6 +569,83 @@ def research_layer_cases():
     return cases
 
 
+class _StubEmb(torch.nn.Module):
+    """stand-in EmbeddingModule of the top-level HSTU model (the test rebuilds it with the same values)"""
+    item_embedding_dim = 32
+
+    def __init__(self, n_items=50, dim=32):
+        super().__init__()
+        self._item_emb = torch.nn.Embedding(n_items, dim)
+
+    def get_item_embeddings(self, ids):
+        return self._item_emb(ids)
+
+
+class _StubPre(torch.nn.Module):
+    """stand-in InputFeaturesPreprocessorModule: scaled item embeddings + a learned positional table, padded rows zeroed"""
+
+    def __init__(self, n, dim):
+        super().__init__()
+        self._pos = torch.nn.Parameter(0.1 * torch.randn(n, dim))
+
+    def forward(self, past_lengths, past_ids, past_embeddings, past_payloads):
+        B, N, D = past_embeddings.shape
+        x = past_embeddings * (D ** 0.5) + self._pos[:N].unsqueeze(0)
+        valid = (past_ids != 0).unsqueeze(-1).to(x.dtype)
+        return past_lengths, x * valid, valid
+
+
+class _StubPost(torch.nn.Module):
+    """stand-in OutputPostprocessorModule: L2 normalisation (research/modeling/sequential/output_postprocessors.py)"""
+
+    def forward(self, x):
+        return x / torch.clamp(torch.linalg.norm(x, ord=None, dim=-1, keepdim=True), min=1e-6)
+
+
+class _StubSim(torch.nn.Module):
+    def forward(self, query_embeddings, item_embeddings, item_ids=None, **kw):
+        return (query_embeddings.unsqueeze(1) * item_embeddings).sum(-1), {}
+
+
+def hstu_model_cases():
+    """The top-level research model ``HSTU`` (research/modeling/sequential/hstu.py:543-809) with stand-in embedding /
+    preprocessor / postprocessor / similarity modules (defined above; tests/test_research_gpu.py rebuilds them with the
+    saved values): ``forward`` (B, N, D), ``encode`` (B, D), every parameter gradient of a loss on both."""
+    from generative_recommenders.research.modeling.sequential.hstu import HSTU
+
+    cases = []
+    for ci, concat_ua in enumerate([False, True]):
+        gen = torch.Generator().manual_seed(900 + ci)
+        B, N, D, H, A, Ld, out_len = 3, 20, 32, 2, 16, 16, 4
+        torch.manual_seed(21 + ci)
+        model = HSTU(max_sequence_len=N, max_output_len=out_len, embedding_dim=D, num_blocks=2, num_heads=H, linear_dim=Ld,
+                     attention_dim=A, normalization="rel_bias", linear_config="uvqk", linear_activation="silu",
+                     linear_dropout_rate=0.0, attn_dropout_rate=0.0, embedding_module=_StubEmb(50, D),
+                     similarity_module=_StubSim(), input_features_preproc_module=_StubPre(N + out_len, D),
+                     output_postproc_module=_StubPost(), concat_ua=concat_ua, verbose=False)
+        with torch.no_grad():
+            for prm in model.parameters():
+                prm.add_(0.05 * torch.randn(prm.shape, generator=gen))
+        Nt = N + out_len
+        lengths = torch.tensor([Nt, 7, 13])
+        ids = torch.randint(1, 50, (B, Nt), generator=gen)
+        ids = ids * (torch.arange(Nt).unsqueeze(0) < lengths.unsqueeze(1))     # padded positions: id 0
+        ts = torch.sort(torch.randint(0, 10**7, (B, Nt), generator=gen), dim=1).values
+        emb = model.get_item_embeddings(ids)
+        y = model(past_lengths=lengths, past_ids=ids, past_embeddings=emb, past_payloads={"timestamps": ts})
+        cur = model.encode(past_lengths=lengths, past_ids=ids, past_embeddings=emb, past_payloads={"timestamps": ts})
+        gy = torch.randn(y.shape, generator=gen)
+        gc = torch.randn(cur.shape, generator=gen)
+        ((y * gy).sum() + (cur * gc).sum()).backward()
+        d = dict(concat_ua=int(concat_ua), B=B, N=N, out_len=out_len, D=D, H=H, A=A, Ld=Ld, lengths=_np(lengths), ids=_np(ids),
+                 ts=_np(ts), y=_np(y), cur=_np(cur), gy=_np(gy), gc=_np(gc))
+        for name, prm in model.named_parameters():
+            d["p:" + name] = _np(prm)
+            d["g:" + name] = _np(prm.grad)
+        cases.append(d)
+    return cases
+
+
 def _save_cases(path, cases):
     flat = {}
     for i, c in enumerate(cases):
@@ -596,7 +673,7 @@ def main():
         ("compute", lambda: [dict(name=np.asarray(n), **c) for n, c in compute_cases().items()]),
         ("stu", lambda: [stu_case()]), ("research_attention", lambda: [research_case()]), ("position", position_cases),
         ("postprocess", postprocess_cases), ("sampled_softmax", sampled_softmax_cases),
-        ("metric_shapes", metric_shape_cases), ("research_layer", research_layer_cases),
+        ("metric_shapes", metric_shape_cases), ("research_layer", research_layer_cases), ("hstu_model", hstu_model_cases),
     ]
     for name, fn in jobs:
         if only and name not in only:

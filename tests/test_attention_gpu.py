@@ -383,6 +383,20 @@ def test_torch_library_operator_seam():
     res = torch.ops.hstu.hstu_mha_bwd(c["N"], c["alpha"], do, q.detach(), k.detach(), v.detach(), dq, dk, dv, off, True,
                                       nt, None, c["w"], 0, 0, False, False, 0)
     assert torch.equal(res[0], q2.grad) and torch.equal(dk, k2.grad) and torch.equal(dv, v2.grad)
+    # deterministic=True (flash_api.cpp:291): one key block = fixed summation order: accepted and bit-identical run to run ...
+    r1 = torch.ops.hstu.hstu_mha_bwd(c["N"], c["alpha"], do, q.detach(), k.detach(), v.detach(), torch.empty_like(q), torch.empty_like(k),
+                                     torch.empty_like(v), off, True, nt, None, c["w"], 0, 0, False, True, 0)
+    assert torch.equal(r1[0], q2.grad) and torch.equal(r1[1], k2.grad) and torch.equal(r1[2], v2.grad)
+    # ... several key blocks (fp32 atomics into the dq accumulator): refused, not silently ignored
+    Nl = 600
+    offl = torch.tensor([0, Nl], device=DEV)
+    ql = torch.randn(Nl, 2, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="deterministic=True is not available"):
+        torch.ops.hstu.hstu_mha_bwd(Nl, 0.1, ql, ql, ql, ql, torch.empty_like(ql), torch.empty_like(ql), torch.empty_like(ql), offl, True,
+                                    None, None, 0, 0, 0, False, True, 0)
+    res_l = torch.ops.hstu.hstu_mha_bwd(Nl, 0.1, ql, ql, ql, ql, torch.empty_like(ql), torch.empty_like(ql), torch.empty_like(ql), offl,
+                                        True, None, None, 0, 0, 0, False, False, 0)
+    assert all(bool(torch.isfinite(t.float()).all()) for t in res_l)
     x = torch.tensor([3, 0, 5], device=DEV)
     assert torch.ops.hstu.complete_cumsum(x).tolist() == [0, 3, 3, 8]
     assert torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach().to("meta"), k.detach().to("meta"),

@@ -282,6 +282,72 @@ def test_research_layer_stack_incremental_and_no_timestamps(idx):
     assert all(layer._rel_attn_bias._pos_w.grad is None and layer._rel_attn_bias._ts_w.grad is None for layer in model._attention_layers)
 
 
+class _StubEmb(torch.nn.Module):          # the stand-in modules of tests/golden/make_golden.py::hstu_model_cases, restated
+    item_embedding_dim = 32
+
+    def __init__(self, n_items=50, dim=32):
+        super().__init__()
+        self._item_emb = torch.nn.Embedding(n_items, dim)
+
+    def get_item_embeddings(self, ids):
+        return self._item_emb(ids)
+
+
+class _StubPre(torch.nn.Module):
+    def __init__(self, n, dim):
+        super().__init__()
+        self._pos = torch.nn.Parameter(torch.zeros(n, dim))
+
+    def forward(self, past_lengths, past_ids, past_embeddings, past_payloads):
+        B, N, D = past_embeddings.shape
+        x = past_embeddings * (D ** 0.5) + self._pos[:N].unsqueeze(0)
+        valid = (past_ids != 0).unsqueeze(-1).to(x.dtype)
+        return past_lengths, x * valid, valid
+
+
+class _StubPost(torch.nn.Module):
+    def forward(self, x):
+        return x / torch.clamp(torch.linalg.norm(x, ord=None, dim=-1, keepdim=True), min=1e-6)
+
+
+class _StubSim(torch.nn.Module):
+    def forward(self, query_embeddings, item_embeddings, item_ids=None, **kw):
+        return (query_embeddings.unsqueeze(1) * item_embeddings).sum(-1), {}
+
+
+@pytest.mark.parametrize("idx", range(2))
+def test_hstu_model_golden_forward_encode_backward(idx):
+    """The top-level research model (research/modeling/sequential/hstu.py:543-809) against reference-minted vectors:
+    ``forward`` (B, N, D), ``encode`` (B, D) and EVERY parameter gradient (embedding table, preprocessor, both layers incl.
+    their bias tables) of a loss on both outputs; fp32."""
+    m = _mods()
+    c = load_cases("hstu_model.npz")[idx]
+    N, out_len, D = int(c["N"]), int(c["out_len"]), int(c["D"])
+    model = m.HSTU(max_sequence_len=N, max_output_len=out_len, embedding_dim=D, num_blocks=2, num_heads=int(c["H"]),
+                   linear_dim=int(c["Ld"]), attention_dim=int(c["A"]), normalization="rel_bias", linear_config="uvqk",
+                   linear_activation="silu", linear_dropout_rate=0.0, attn_dropout_rate=0.0, embedding_module=_StubEmb(50, D),
+                   similarity_module=_StubSim(), input_features_preproc_module=_StubPre(N + out_len, D),
+                   output_postproc_module=_StubPost(), concat_ua=bool(int(c["concat_ua"])), verbose=False)
+    params = dict(model.named_parameters())
+    names = sorted(k[2:] for k in c if k.startswith("p:"))
+    assert sorted(params) == names, "parameter names = the reference's"
+    with torch.no_grad():
+        for k in names:
+            params[k].copy_(torch.from_numpy(c["p:" + k]))
+    model = model.to(DEV)
+    lengths = torch.from_numpy(c["lengths"]).to(DEV)
+    ids = torch.from_numpy(c["ids"]).to(DEV)
+    ts = torch.from_numpy(c["ts"]).to(DEV)
+    emb = model.get_item_embeddings(ids)
+    y = model(past_lengths=lengths, past_ids=ids, past_embeddings=emb, past_payloads={"timestamps": ts})
+    cur = model.encode(past_lengths=lengths, past_ids=ids, past_embeddings=emb, past_payloads={"timestamps": ts})
+    _close(y, c["y"], 1e-3, 1e-5, "HSTU.forward")
+    _close(cur, c["cur"], 1e-3, 1e-5, "HSTU.encode")
+    ((y * torch.from_numpy(c["gy"]).to(DEV)).sum() + (cur * torch.from_numpy(c["gc"]).to(DEV)).sum()).backward()
+    for name, prm in model.named_parameters():
+        _close(prm.grad, c["g:" + name], 2e-3, 2e-5, "HSTU grad " + name)
+
+
 def test_hstu_model_mirror_runs_with_duck_typed_modules():
     """HSTU (hstu.py:543-809): constructor arguments, state_dict names and the encode / forward methods, with stand-in
     embedding / preprocessor / postprocessor / similarity modules."""
