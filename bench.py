@@ -490,7 +490,7 @@ def attach_traffic(res, args, att):
     counters cannot be read from inside the process) -- attached only when the run's workload, users, head dim and
     dtype are the ones the passes were taken on"""
     res["roofline"]["traffic"] = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             tr = json.load(open(path))

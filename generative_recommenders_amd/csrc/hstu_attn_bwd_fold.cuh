@@ -42,6 +42,12 @@
 #define FOLD_ABLATE 0      // timing experiments only (WRONG results; tools/ab_bwd.py): 1 no dQ stores, 2 no dk/dv
 #endif                     // stores, 4 no stage DMA after step 0, 8 no tail, 16 no K/V DMA, 32 no dQ GEMM, 64 no pairs,
                            // 128 / 256 every problem aliases one of the first 256 / 32 (Infinity-Cache / L2 resident data)
+#ifndef FOLD_PARK_SWAP
+#define FOLD_PARK_SWAP 0   // parked dk / dv tiles: 8-byte halves flipped on rows with bit 1 set (conflict-free ds_write_b64)
+#endif
+#ifndef FOLD_DQ_CONTIG
+#define FOLD_DQ_CONTIG 1   // dQ GEMM: 16 contiguous features per MFMA (conflict-free K reads) + v_permlane16_swap
+#endif
 #ifndef FOLD_DMA_FAST
 #define FOLD_DMA_FAST 1    // LDS-DMA source addresses as scalar base + 32-bit lane offset (3 instead of ~20 VALU per chunk)
 #endif
@@ -361,7 +367,11 @@ HSTU_DEV void fold_park_tile(const f32x16 (&acc)[D / 32], float scale, char* __r
     for (int rq = 0; rq < 4; ++rq) {
       u32x2 v = {Elem<T>::pk2(acc[d][4 * rq] * scale, acc[d][4 * rq + 1] * scale),
                  Elem<T>::pk2(acc[d][4 * rq + 2] * scale, acc[d][4 * rq + 3] * scale)};
-      *LDS_PTR(u32x2, tile + tile_off<UPR>(n32, 4 * d + rq) + 8 * hf) = v;
+      // (256-byte rows: the 16 lanes of a ds_write_b64 group -- 16 rows, one unit column, one hf -- hit every 16-byte slot
+      // class mod 8 twice; flipping the 8-byte half on the rows whose swizzle has bit 3 set, i.e. row bit 1, makes them 16
+      // different 8-byte columns of the 128-byte write window.  fold_copy_out flips them back.)
+      const int half = (FOLD_PARK_SWAP && UPR >= 16) ? (hf ^ ((n32 >> 1) & 1)) : hf;
+      *LDS_PTR(u32x2, tile + tile_off<UPR>(n32, 4 * d + rq) + 8 * half) = v;
     }
 }
 template <typename T, int D>
@@ -369,7 +379,8 @@ HSTU_DEV void fold_copy_out(const char* __restrict__ tile, char* gtile, int64_t 
   constexpr int UPR = D * Elem<T>::kBytes / 16;
   for (int u = tid; u < 32 * UPR; u += kBwdThreads) {
     const int row = u / UPR, unit = u % UPR;
-    const u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, unit));
+    u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, unit));
+    if (FOLD_PARK_SWAP && UPR >= 16 && ((row >> 1) & 1)) v = u32x4{v[2], v[3], v[0], v[1]};     // (see fold_park_tile)
     if (row < rows_valid && (!(FOLD_ABLATE & 2) || row_stride_bytes == -12345)) gstore16(gtile + row * row_stride_bytes + unit * 16, v);
   }
 }
@@ -437,7 +448,15 @@ HSTU_DEV void fold_dq_slots(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
   if (db >= DQK / 32) return;
   const int i16 = lane & 15, g = lane >> 4;
   const int row_lo = 8 * g + (i16 >> 2), row_hi = row_lo + 4;
-  const int colK0 = 32 * db + 8 * (i16 & 3), colK1 = colK0 + 4;
+  // Which 16 features an MFMA covers.  Interleaved in groups of 4 (MFMA h: features 8 m' + 4 h + r), a lane ends up with 8
+  // consecutive features -- but then MFMA h's transposed K reads touch only half h of every 16-byte unit, the two 16-lane
+  // groups of a 32-lane read pass land on the same 16 eight-byte slots of the bank window, and EVERY K read of the dQ GEMM is
+  // a 2-way bank conflict (two thirds of the kernel's SQ_LDS_BANK_CONFLICT, profiles/r02_*).  With 256-byte rows (head dim
+  // 128) MFMA h takes 16 CONTIGUOUS features instead (32 bytes per row: the pass covers all 256 bytes of the window, no
+  // conflict), and the results of the two MFMAs are exchanged between lane groups g and g ^ 1 with v_permlane16_swap so that a
+  // lane still stores 8 consecutive features (fold_dq_store).  Same contractions in the same order: bit-identical.
+  constexpr bool kContig = FOLD_DQ_CONTIG && C::UPR_K == 16;
+  const int colK0 = kContig ? 32 * db + 4 * (i16 & 3) : 32 * db + 8 * (i16 & 3), colK1 = colK0 + (kContig ? 16 : 4);
   const int k0_lo = tile_off<C::UPR_K>(row_lo, colK0 >> 3) + ((colK0 & 7) << 1);
   const int k0_hi = tile_off<C::UPR_K>(row_hi, colK0 >> 3) + ((colK0 & 7) << 1);
   const int k1_lo = tile_off<C::UPR_K>(row_lo, colK1 >> 3) + ((colK1 & 7) << 1);
@@ -493,16 +512,27 @@ HSTU_DEV void fold_dq_slots(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
     }
   }
   HSTU_MARK(16);
-  // C layout of MFMA h: column i16 = query row, register r = feature 32 db + 8 g + 4 h + r
+  // C layout of MFMA h: column i16 = query row, register r = feature 32 db + 8 g + 4 h + r (interleaved) or
+  // 32 db + 16 h + 4 g + r (contiguous)
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) {
-    if (sd == 1 && !b_on) break;
+    if (sd == 1 && !b_on) break;     // (wave-uniform: the lane exchange below runs with all lanes)
+    uint32_t x0 = E::pk2(acc[sd][0][0] * ds_scale, acc[sd][0][1] * ds_scale), x1 = E::pk2(acc[sd][0][2] * ds_scale, acc[sd][0][3] * ds_scale);
+    uint32_t y0 = E::pk2(acc[sd][1][0] * ds_scale, acc[sd][1][1] * ds_scale), y1 = E::pk2(acc[sd][1][2] * ds_scale, acc[sd][1][3] * ds_scale);
+    int f0 = 8 * g;                  // first of the lane's 8 consecutive features
+    if constexpr (kContig) {
+      // MFMA 0 holds features 4 g + r, MFMA 1 features 16 + 4 g + r of the wave's 32.  v_permlane16_swap exchanges the odd lane
+      // groups of its first operand with the even ones of its second: afterwards lane group g holds the 8 features from
+      // 8 (2 (g & 1) + (g >> 1)) on -- x: the lower four, y: the upper four
+      const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+      x0 = s0[0]; y0 = s0[1]; x1 = s1[0]; y1 = s1[1];
+      f0 = 8 * (2 * (g & 1) + (g >> 1));
+    }
     const int qrow = 32 * (sd ? bq : a) + 16 * qb + i16;
     if (qrow < mc.len && (!(FOLD_ABLATE & 1) || bp.total_rows == -12345)) {
       char* dqrow = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB;
-      u32x4 v = {E::pk2(acc[sd][0][0] * ds_scale, acc[sd][0][1] * ds_scale), E::pk2(acc[sd][0][2] * ds_scale, acc[sd][0][3] * ds_scale),
-                 E::pk2(acc[sd][1][0] * ds_scale, acc[sd][1][1] * ds_scale), E::pk2(acc[sd][1][2] * ds_scale, acc[sd][1][3] * ds_scale)};
-      gstore16(dqrow + (32 * db + 8 * g) * C::EB, v);
+      gstore16(dqrow + (32 * db + f0) * C::EB, u32x4{x0, x1, y0, y1});
     }
   }
 }
