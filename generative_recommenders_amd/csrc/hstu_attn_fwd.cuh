@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   // flight while tile t is computed; one raw barrier per tile, loads are never drained in the loop
   // The source address of a chunk is (uniform tile base) + (row of the lane) x (row stride) + (swizzled unit) x 16.  Written
   // naively that is ~20 VALU instructions per chunk -- a 64-bit multiply-add among them -- i.e. 80 per key tile and wave next
-  // to the ~90 of the tile's element-wise block, in a kernel whose SIMDs are VALU-issue bound (`profiles/r03_fwd_valu.md`).
+  // to the ~90 of the tile's element-wise block (docs/EXPERIMENTS.md A.2: 1.400 -> 1.336 ms).
   // The lane's row inside the tile and its unit's byte offset never change: they are planned once per head, and a chunk
   // costs an add, a min and one 24-bit multiply-add into a 32-bit offset from the head's (scalar) base pointer.  Needs the
   // user's rows to span < 4 GiB and strides < 16 MiB (else the general path).

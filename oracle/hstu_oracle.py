@@ -550,7 +550,7 @@ def dropout_keep_mask(seed: int, rows: int, out_stride: int, dropout_ratio: floa
     What is restated: the SEMANTICS of the reference's in-kernel dropout (triton_hstu_linear.py:101-120 /
     pt_hstu_linear.py:60-64: every element of the concatenated output is dropped independently with probability p and
     survivors are scaled by 1 / (1 - p); the backward reuses the mask) and, bit for bit, the counter-based generator of
-    the HIP kernels (csrc/norm_ops.hip, drop_hash) -- the reference's own Philox stream (tl.rand / F.dropout) is not
+    the HIP kernels (csrc/norm_kernels.inc, drop_hash) -- the reference's own Philox stream (tl.rand / F.dropout) is not
     reproducible across implementations, so parity under dropout is (a) this exact mask and (b) the statistics.
     Element e = row * out_stride + col; pair j = e >> 1 shares one 32-bit hash, element e takes its low (e even) or
     high (e odd) 16 bits; keep iff r16 >= thr, thr = clamp(round(p * 65536), 1, 65535); scale = 65536 / (65536 - thr).

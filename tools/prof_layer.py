@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 
-args = argparse.Namespace(max_seq_len=200, heads=4, head_dim=128, layer_users_per_gpu=1024, layer_steps=5)
+args = argparse.Namespace(max_seq_len=200, heads=4, head_dim=128, layer_users_per_gpu=1024, layer_steps=5, layer_dropout=0.1)
 dev = torch.device("cuda", 0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
