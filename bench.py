@@ -348,6 +348,12 @@ def layer_section(args, rank, world, device):
         return dp.max_over_ranks(time.perf_counter() - t0, device), stack
 
     p_drop = args.layer_dropout
+    if getattr(args, "layer_tunableop", False):
+        import torch.cuda.tunable as tunable
+
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(200)
     elapsed_keep, _ = timed(False, p_drop)
     elapsed_nodrop, _ = timed(True, 0.0)
     elapsed, stack = timed(True, p_drop)
@@ -355,6 +361,7 @@ def layer_section(args, rank, world, device):
     gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
     return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,
                 user_seqs_per_s=world * B * args.layer_steps / elapsed, params=nparams,
+                gemm_selection="TunableOp" if getattr(args, "layer_tunableop", False) else "hipBLASLt heuristic (default)",
                 config=f"3 STU layers D=512, 4 heads of 128, group norm, targets; training mode, output_dropout_ratio={p_drop} "
                        f"(fused, mask regenerated in backward), recompute normed_x / uvqk / y in backward; gradient all-reduce: "
                        f"one bucket per layer launched from backward hooks",
@@ -664,6 +671,9 @@ def main():
     ap.add_argument("--layer-steps", type=int, default=10)
     ap.add_argument("--layer-dropout", type=float, default=0.1, help="output_dropout_ratio of the layer section (DLRM-v3: 0.1)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other workloads (extra_workloads)")
+    ap.add_argument("--layer-tunableop", action="store_true",
+                    help="let PyTorch's TunableOp pick the hipBLASLt / rocBLAS solution of the layer section's six GEMM shapes during its "
+                         "warm-up (~20 s; measured 15.1 -> 14.5 ms per step, profiles/r03_layer_tunableop.txt); off by default")
     ap.add_argument("--extra-steps", type=int, default=8)
     ap.add_argument("--cpu-users", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=32)

@@ -32,6 +32,9 @@ constexpr int kFwdThreads = 256;
 #ifndef FWD_DMA_ASM
 #define FWD_DMA_ASM 1       // the planned DMA path issues its instruction through inline asm (see dma16_saddr_asm)
 #endif
+#ifndef FWD_K_EARLY
+#define FWD_K_EARLY 0       // K tiles run three ahead: K(t+3) is requested in the MIDDLE of step t (second barrier, after the S chains)
+#endif
 #ifndef FWD_DMA_FIRST
 #define FWD_DMA_FIRST 0     // the first K/V tiles are requested before the Q rows (prologue: one memory round trip instead of two)
 #endif
@@ -386,7 +389,29 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     tile_dma<T, DQK>(st, kbase, k_rs, kv_lo + 32 * t, len, p.dqk, wave, 4, lane);
     tile_dma<T, DV>(st + C::KT, vbase, v_rs, kv_lo + 32 * t, len, p.dv, wave, 4, lane);
   };
-  for (int t = 0; t < C::NS - 1 && t < ntiles; ++t) issue_tile(t, t);
+  // FWD_K_EARLY.  What a step waits for is its K tile (the V tile is needed ~1.8 K cycles later), and with the whole tile
+  // requested two steps ahead K's lead (~6.8 K cycles) is just short of the DMA's ~7 K cycles: every step began with ~0.8 K
+  // cycles of waiting (profiles/r03_fwd_trace_after.txt).  The K half of a ring slot is dead as soon as every wave has run its
+  // S chain: a second barrier in the middle of the step frees it, and K(t+3) goes out there -- K three tiles ahead, V two, and
+  // ~12 % more bytes in flight per workgroup in the same 48 KiB.  MEASURED: bit-identical and 0.7 % (head dim 128) / 3 % (64)
+  // SLOWER -- the second barrier costs more than the lead buys (profiles/r03_ab_fwd_k_early.txt): off.
+  constexpr bool k_early = FWD_K_EARLY && !BIAS && C::NS == 3 && C::COUNTED;     // (a property of the instantiation)
+#define HSTU_ISSUE_K(t_, slot_)                                                                                              \
+  do {                                                                                                                       \
+    if (dma_fast) tile_dma_fast<NIK>(smem + (slot_) * C::STAGE, kbase, (uint32_t)k_rs, kv_lo + 32 * (t_), len, plk, wave, 4); \
+    else tile_dma<T, DQK>(smem + (slot_) * C::STAGE, kbase, k_rs, kv_lo + 32 * (t_), len, p.dqk, wave, 4, lane);             \
+  } while (0)
+#define HSTU_ISSUE_V(t_, slot_)                                                                                                       \
+  do {                                                                                                                                \
+    if (dma_fast) tile_dma_fast<NIV>(smem + (slot_) * C::STAGE + C::KT, vbase, (uint32_t)v_rs, kv_lo + 32 * (t_), len, plv, wave, 4); \
+    else tile_dma<T, DV>(smem + (slot_) * C::STAGE + C::KT, vbase, v_rs, kv_lo + 32 * (t_), len, p.dv, wave, 4, lane);                \
+  } while (0)
+  if constexpr (k_early) {
+    for (int t = 0; t < 2 && t < ntiles; ++t) { HSTU_ISSUE_K(t, t); HSTU_ISSUE_V(t, t); }
+    if (2 < ntiles) HSTU_ISSUE_K(2, 2);
+  } else {
+    for (int t = 0; t < C::NS - 1 && t < ntiles; ++t) issue_tile(t, t);
+  }
   if (FWD_DMA_FIRST) HSTU_FWD_LOAD_Q()
 #undef HSTU_FWD_LOAD_Q
   HSTU_MARK(3);
@@ -398,15 +423,25 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
     const int j0 = kv_lo + (t << 5);
     // tile t has landed once at most (tiles issued after it) * PER_TILE DMA instructions are pending
     if constexpr (C::COUNTED) {
-      const int newer = min(C::NS - 2, ntiles - 1 - t);     // tiles issued after tile t so far
-      if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_TILE) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (k_early) {      // requested after V(t), in this order: K(t+1), V(t+1), K(t+2)
+        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIK + NIV) : "memory");
+        else if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIK + NIV) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        const int newer = min(C::NS - 2, ntiles - 1 - t);     // tiles issued after tile t so far
+        if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // every wave's chunks of tile t landed; stage (t-1) % NS is free
     asm volatile("" ::: "memory");
-    if (t + C::NS - 1 < ntiles) issue_tile(t + C::NS - 1, (slot + C::NS - 1) % C::NS);
+    if constexpr (k_early) {
+      if (t + 2 < ntiles) HSTU_ISSUE_V(t + 2, (slot + 2) % C::NS);
+    } else {
+      if (t + C::NS - 1 < ntiles) issue_tile(t + C::NS - 1, (slot + C::NS - 1) % C::NS);
+    }
     HSTU_MARK(10);
     // (scalar work is not free: the general tile predicates cost ~100 SALU instructions per tile; plain-causal
     // batches -- no targets, window or contextual rows -- take two compares instead)
@@ -419,6 +454,17 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       tile_act = mc.pair_may_be_active(i0w, 32, j0, 32);
       tile_full = tile_act && mc.pair_fully_valid(i0w, 32, j0, 32);
     }
+    // (the middle-of-step barrier of FWD_K_EARLY sits INSIDE the active branch, with a twin in the else branch: every wave
+    // executes exactly one of them per step.  Splitting the branch in two around one barrier costs 16 registers.)
+#define HSTU_MID_STEP()                                                          \
+  do {                                                                           \
+    if constexpr (k_early) {                                                     \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
+      __builtin_amdgcn_s_barrier();                                              \
+      asm volatile("" ::: "memory");                                             \
+      if (t + 3 < ntiles) HSTU_ISSUE_K(t + 3, slot);                             \
+    }                                                                            \
+  } while (0)
     if (wave_active && tile_act && !(FWD_ABLATE & 2)) {
       const char* Kt = smem + slot * C::STAGE;
       const char* Vt = Kt + C::KT;
@@ -447,6 +493,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = ((r & 3) + 8 * (r >> 2) > x) ? neg : s[r];
       }
+      HSTU_MID_STEP();      // every wave has read the K tile (its LDS reads retired before the MFMAs issued): that half of the slot is free
       HSTU_MARK(11);
       Frag pb[2];
 #pragma unroll
@@ -540,7 +587,10 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
           oacc[d] = E::mma(a, pb[ks], oacc[d]);
         }
       }
+    } else {
+      HSTU_MID_STEP();
     }
+#undef HSTU_MID_STEP
     HSTU_MARK(14);
   }
   HSTU_MARK(20);
