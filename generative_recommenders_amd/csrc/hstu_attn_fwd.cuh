@@ -32,6 +32,9 @@ constexpr int kFwdThreads = 256;
 #ifndef FWD_DMA_ASM
 #define FWD_DMA_ASM 1       // the planned DMA path issues its instruction through inline asm (see dma16_saddr_asm)
 #endif
+#ifndef FWD_WAVE_FLIP
+#define FWD_WAVE_FLIP 1
+#endif
 #ifndef FWD_K_EARLY
 #define FWD_K_EARLY 0       // K tiles run three ahead: K(t+3) is requested in the MIDDLE of step t (second barrier, after the S chains)
 #endif
@@ -276,7 +279,13 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   HSTU_TRACE_DECL(g_hstu_trace_fwd + (blockIdx.x == 4104 ? 4 * 256 : 0), g_hstu_trace_fwd != nullptr && (blockIdx.x == 4096 || blockIdx.x == 4104));
 #endif
   HSTU_MARK(1);
-  const int r0 = q0 + 32 * wave;                 // first q row of this wave
+  // Which 32 rows of the block the wave owns.  Wave w of a workgroup runs on SIMD w, and with plain causal masks the
+  // row tile 4 qb + w costs 4 qb + w + 1 key tiles: every workgroup puts its lightest tile on SIMD 0 and its heaviest on
+  // SIMD 3.  FWD_WAVE_FLIP: odd query blocks hand their row tiles out in reverse (among the waves that have rows), so
+  // that the two blocks of a 200-row sequence load the SIMDs 1+7, 2+6, 3+5, 4+0 instead of 1+5, 2+6, 3+7, 4+0.
+  const int na_blk = (min(kFwdRowsPerBlock, nq_rows - q0) + 31) >> 5;
+  const int vw = (FWD_WAVE_FLIP && (qb & 1) && wave < na_blk) ? na_blk - 1 - wave : wave;
+  const int r0 = q0 + 32 * vw;                   // first q row of this wave
   const bool wave_active = r0 < nq_rows;
   const int my_row = r0 + n32;
   const bool row_ok = my_row < nq_rows;
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
   const int ntiles = (kv_hi - kv_lo + 31) >> 5;
 
   // bucket bytes of this wave: tiles 0 .. (4 qb + wave) of its query tile, behind those of the waves before it
-  char* const bcache = smem + C::SMEM + bucket_cache_off + (wave * (4 * qb + 1) + ((wave * (wave - 1)) >> 1)) * 1024;
+  char* const bcache = smem + C::SMEM + bucket_cache_off + (vw * (4 * qb + 1) + ((vw * (vw - 1)) >> 1)) * 1024;
 
   const int lane_wg = lane;
   for (int hi = 0; hi < n_heads; ++hi) {

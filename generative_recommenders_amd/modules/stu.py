@@ -165,14 +165,14 @@ class STULayer(STU):
         with record_function("## stu_preprocess_and_attention ##"):
             u, attn_output, k, v = hstu_preprocess_and_attention(
                 x=x,
-                norm_weight=self._input_norm_weight.to(x.dtype),
-                norm_bias=self._input_norm_bias.to(x.dtype),
+                norm_weight=self._input_norm_weight,
+                norm_bias=self._input_norm_bias,
                 norm_eps=1e-6,
                 num_heads=self._num_heads,
                 attn_dim=self._attention_dim,
                 hidden_dim=self._hidden_dim,
-                uvqk_weight=self._uvqk_weight.to(x.dtype),
-                uvqk_bias=self._uvqk_beta.to(x.dtype),
+                uvqk_weight=self._uvqk_weight,
+                uvqk_bias=self._uvqk_beta,
                 max_seq_len=max_seq_len,
                 seq_offsets=x_offsets,
                 attn_alpha=self._attn_alpha,
@@ -194,11 +194,11 @@ class STULayer(STU):
     def _output(self, attn: torch.Tensor, u: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         return hstu_compute_output(
             attn=attn, u=u, x=x,
-            norm_weight=self._output_norm_weight.to(x.dtype),
-            norm_bias=self._output_norm_bias.to(x.dtype),
+            norm_weight=self._output_norm_weight,
+            norm_bias=self._output_norm_bias,
             norm_eps=1e-6,
             dropout_ratio=self._output_dropout_ratio,
-            output_weight=self._output_weight.to(x.dtype),
+            output_weight=self._output_weight,
             group_norm=self._use_group_norm,
             num_heads=self._num_heads,
             linear_dim=self._hidden_dim,

@@ -34,6 +34,7 @@ def hstu_compute_uqvk(
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """LN_affine(x) @ W + b, split as [u, v, q, k], SiLU on u only."""
     del kernel
+    norm_weight, norm_bias, uvqk_weight, uvqk_bias = (t.to(x.dtype) for t in (norm_weight, norm_bias, uvqk_weight, uvqk_bias))
     normed_x = layer_norm(x, weight=norm_weight, bias=norm_bias, eps=norm_eps)
     uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
     u, v, q, k = torch.split(
@@ -62,6 +63,15 @@ def draw_dropout_seed() -> int:
     """The seed of one fused-dropout call, drawn the way the reference draws it (triton_hstu_linear.py:376-377: torch's
     default CPU generator, no device sync) -- ``torch.manual_seed`` makes a run reproducible."""
     return int(torch.randint(low=0, high=2**62, size=(1,), dtype=torch.int64).item())
+
+
+def _cast(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """A parameter in the activations' dtype.  The fused nodes take the module's parameters AS THEY ARE (fp32 masters next
+    to bf16 activations): one cast per parameter and forward inside the node, the casted copy saved for backward, and the
+    gradient -- which the kernels and the split weight-gradient GEMM produce in fp32 anyway -- returned in the
+    parameter's dtype without a detour through bf16 (a ``.to()`` outside the node costs a second cast kernel in forward's
+    recompute, one more in backward, and rounds the gradient to bf16 on the way)."""
+    return t if t.dtype == dtype else t.detach().to(dtype)
 
 
 class _NormMulFunction(torch.autograd.Function):
@@ -95,6 +105,8 @@ class _ComputeOutputFunction(torch.autograd.Function):
         # dropout (training): inside the norm kernel, on all of [u, attn, u * Norm(attn)] as the reference's
         # _ln_mul_dropout_fwd does (triton_hstu_linear.py:101-120); the mask is never stored -- the backward kernel and the
         # recompute of y regenerate it from the seed
+        ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, output_weight.dtype)
+        norm_weight, norm_bias, output_weight = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, output_weight))
         y, mean, rstd = _launch.norm_mul_fwd(attn, u, norm_weight, norm_bias, eps, num_heads, linear_dim, group_norm,
                                              concat_ux, dropout_ratio, seed)
         out = torch.addmm(x, y, output_weight)
@@ -114,10 +126,11 @@ class _ComputeOutputFunction(torch.autograd.Function):
         else:
             y = ctx.saved_tensors[7]
         dout = dout.contiguous()
+        nw_dtype, nb_dtype, wo_dtype = ctx.param_dtypes
         dy = torch.mm(dout, Wo.t())
-        dWo = weight_grad_mm(y, dout)
+        dWo = weight_grad_mm(y, dout, out_dtype=wo_dtype)
         dattn, du, dnw, dnb = _launch.norm_mul_bwd(dy, attn, u, nw, nb, mean, rstd, H, Ld, gn, cat, p_drop, seed)
-        return (dattn, du, dout, dnw.to(nw.dtype), dnb.to(nb.dtype), dWo, None, None, None, None, None, None, None,
+        return (dattn, du, dout, dnw.to(nw_dtype), dnb.to(nb_dtype), dWo, None, None, None, None, None, None, None,
                 None)
 
 
@@ -156,6 +169,9 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
     def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, seq_offsets, num_targets, norm_eps,
                 num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
                 recompute_uvqk, recompute_normed_x, user_order=None):
+        ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
+        norm_weight, norm_bias, uvqk_weight, uvqk_bias = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_weight,
+                                                                                       uvqk_bias))
         normed_x, mean, rstd = _launch.layer_norm_fwd(x, norm_weight, norm_bias, norm_eps)
         uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
@@ -206,11 +222,12 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         _launch.attn_bwd(dout.reshape(-1, H, Hd), q, k, v, seq_offsets, num_targets, N, alpha, 1.0 / N, w, c, 0,
                          dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         _launch.silu_bwd(du, uvqk[:, :hv], din=duvqk[:, :hv])
+        nw_dtype, nb_dtype, w_dtype, beta_dtype = ctx.param_dtypes
         d_normed = torch.mm(duvqk, W.t())
-        dW = weight_grad_mm(normed_x, duvqk)
-        dbeta = duvqk.sum(dim=0)
+        dW = weight_grad_mm(normed_x, duvqk, out_dtype=w_dtype)
+        dbeta = duvqk.sum(dim=0, dtype=torch.float32 if beta_dtype == torch.float32 else None)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
-        return (dx, dnw.to(nw.dtype), dnb.to(nb.dtype), dW, dbeta.to(beta.dtype), None, None, None, None, None, None,
+        return (dx, dnw.to(nw_dtype), dnb.to(nb_dtype), dW, dbeta.to(beta_dtype), None, None, None, None, None, None,
                 None, None, None, None, None, None, None)
 
 

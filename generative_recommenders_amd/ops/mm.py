@@ -2,6 +2,8 @@
 GEMMs: they go to hipBLASLt through ``torch.addmm`` -- exactly what the reference itself
 does on AMD (ops/hstu_compute.py:69-72, ops/triton/triton_hstu_linear.py:1191-1194)."""
 
+from typing import Optional
+
 import torch
 
 from generative_recommenders_amd.common import HammerKernel
@@ -34,7 +36,7 @@ def _bmm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.bmm(a.float(), b.float())
 
 
-def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """``x^T dy`` for x (L, K), dy (L, N): the weight gradient of ``y = x W``.  The contraction runs over ALL jagged
     rows (L ~ 10^5..10^6) while the result is one small (K, N) matrix: as a single GEMM that is K N / (128 x 256)
     output tiles -- 32 workgroups on a 256-CU part for the DLRM-v3 projections.  The rows are therefore split into
@@ -46,12 +48,13 @@ def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     # (S x K x N x 4 bytes) would pass 64 MiB
     tiles = -(-K // 256) * -(-N // 256)
     S = min(_SPLIT_SLABS, L // _MIN_SLAB_ROWS, max(1, 256 // tiles), max(1, (64 << 20) // (K * N * 4)))
+    out_dtype = out_dtype or x.dtype
     if not x.is_cuda or S <= 1:
-        return torch.mm(x.t(), dy)
+        return torch.mm(x.t(), dy).to(out_dtype)
     slab = (L // S) // 64 * 64
     main = slab * S
     part = _bmm_f32(x[:main].view(S, slab, K).transpose(1, 2), dy[:main].view(S, slab, N))
     out = part.sum(dim=0)
     if main < L:
         out += torch.mm(x[main:].t(), dy[main:]).float()
-    return out.to(x.dtype)
+    return out.to(out_dtype)

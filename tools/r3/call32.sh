@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out/r3
+python -m pytest tests/test_compute_gpu.py tests/test_dropout_gpu.py tests/test_research_gpu.py tests/test_configs_gpu.py -m gpu -x -q 2>&1 | tail -8
+python bench.py --no-extra --no-cpu --steps 10 --warmup 3 > gpurun_out/r3/bench32.json 2> gpurun_out/r3/bench32.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r3/bench32.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['attention'] if 'attention' in d else '')
+l=d.get('layer'); print(l['ms_per_step'], l['dropout_off'], l['no_recompute'])
+PY
