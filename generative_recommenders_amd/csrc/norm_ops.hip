@@ -68,7 +68,14 @@ int hstu_layer_norm_fwd(const void* x, const void* weight, const void* bias, voi
 int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight, const float* mean, const float* rstd,
                         void* dx, float* dweight, float* dbias, float* partial_ws, int64_t rows, int32_t dim, int dtype,
                         void* stream) {
+  return hstu_layer_norm_bwd_residual(dy, x, weight, mean, rstd, nullptr, dx, dweight, dbias, partial_ws, rows, dim, dtype, stream);
+}
+
+int hstu_layer_norm_bwd_residual(const void* dy, const void* x, const void* weight, const float* mean, const float* rstd,
+                                 const void* dresidual, void* dx, float* dweight, float* dbias, float* partial_ws,
+                                 int64_t rows, int32_t dim, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  const void* dres = dresidual;
   if (!dweight || !dbias) return set_error(HSTU_EINVAL, "layer_norm_bwd: dweight/dbias are required");
   if (rows == 0) {
     (void)hipMemsetAsync(dweight, 0, dim * sizeof(float), st);
@@ -77,9 +84,9 @@ int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight, const
   }
   if (!dy || !x || !weight || !mean || !rstd || !dx || !partial_ws) return set_error(HSTU_EINVAL, "layer_norm_bwd: NULL tensor");
   const bool wd = norm_wide(dim, dy, x, dx, dtype == HSTU_DTYPE_F32 ? 4 : 2);
-  DISPATCH_DTYPE(dtype, NW(wd, ln_bwd<bf16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, st)),
-                 NW(wd, ln_bwd<f16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, st)),
-                 NW(wd, ln_bwd<float>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, st)));
+  DISPATCH_DTYPE(dtype, NW(wd, ln_bwd<bf16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, dres, st)),
+                 NW(wd, ln_bwd<f16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, dres, st)),
+                 NW(wd, ln_bwd<float>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, dres, st)));
 }
 
 static int drop_ratio_ok(float r, const char* who) {
@@ -90,13 +97,23 @@ static int drop_ratio_ok(float r, const char* who) {
 int hstu_norm_mul_dropout_fwd(const void* attn, const void* u, const void* weight, const void* bias, void* y, float* mean,
                               float* rstd, int64_t rows, int32_t heads, int32_t head_dim, float eps, int group_norm,
                               int concat_ux, float dropout_ratio, uint64_t seed, int dtype, void* stream) {
+  return hstu_norm_mul_silu_fwd(attn, u, (int64_t)heads * head_dim, 0, weight, bias, y, mean, rstd, rows, heads, head_dim, eps,
+                                group_norm, concat_ux, dropout_ratio, seed, dtype, stream);
+}
+
+int hstu_norm_mul_silu_fwd(const void* attn, const void* u, int64_t u_row_stride, int u_is_preactivation, const void* weight,
+                           const void* bias, void* y, float* mean, float* rstd, int64_t rows, int32_t heads,
+                           int32_t head_dim, float eps, int group_norm, int concat_ux, float dropout_ratio, uint64_t seed,
+                           int dtype, void* stream) {
   if (int e = drop_ratio_ok(dropout_ratio, "norm_mul_dropout_fwd")) return e;
+  if (u_row_stride < (int64_t)heads * head_dim) return set_error(HSTU_EINVAL, "norm_mul_fwd: u_row_stride is smaller than a row");
+  const bool silu = u_is_preactivation != 0;
   if (rows == 0) return HSTU_OK;
   if (!attn || !u || !weight || !bias || !y) return set_error(HSTU_EINVAL, "norm_mul_fwd: NULL tensor");
   hipStream_t st = (hipStream_t)stream;
   const bool wd = norm_wide(heads * head_dim, attn, u, y, dtype == HSTU_DTYPE_F32 ? 4 : 2);
-#define NM_FWD(T) (wd ? nw4::nm_fwd<T>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, nw4::make_drop_ctx(dropout_ratio, seed), st) \
-                      : nw1::nm_fwd<T>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, nw1::make_drop_ctx(dropout_ratio, seed), st))
+#define NM_FWD(T) (wd ? nw4::nm_fwd<T>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, nw4::make_drop_ctx(dropout_ratio, seed), u_row_stride, silu, st) \
+                      : nw1::nm_fwd<T>(attn, u, weight, bias, y, mean, rstd, rows, heads, head_dim, eps, group_norm, concat_ux, nw1::make_drop_ctx(dropout_ratio, seed), u_row_stride, silu, st))
   DISPATCH_DTYPE(dtype, NM_FWD(bf16_t), NM_FWD(f16_t), NM_FWD(float));
 #undef NM_FWD
 }
@@ -120,7 +137,20 @@ int hstu_norm_mul_dropout_bwd(const void* dy, const void* attn, const void* u, c
                               const float* mean, const float* rstd, void* dattn, void* du, float* dweight, float* dbias,
                               float* partial_ws, int64_t rows, int32_t heads, int32_t head_dim, int group_norm,
                               int concat_ux, float dropout_ratio, uint64_t seed, int dtype, void* stream) {
+  const int64_t dim = (int64_t)heads * head_dim;
+  return hstu_norm_mul_silu_bwd(dy, attn, u, dim, 0, weight, bias, mean, rstd, dattn, du, dim, dweight, dbias, partial_ws, rows,
+                                heads, head_dim, group_norm, concat_ux, dropout_ratio, seed, dtype, stream);
+}
+
+int hstu_norm_mul_silu_bwd(const void* dy, const void* attn, const void* u, int64_t u_row_stride, int u_is_preactivation,
+                           const void* weight, const void* bias, const float* mean, const float* rstd, void* dattn, void* du,
+                           int64_t du_row_stride, float* dweight, float* dbias, float* partial_ws, int64_t rows,
+                           int32_t heads, int32_t head_dim, int group_norm, int concat_ux, float dropout_ratio,
+                           uint64_t seed, int dtype, void* stream) {
   if (int e = drop_ratio_ok(dropout_ratio, "norm_mul_dropout_bwd")) return e;
+  if (u_row_stride < (int64_t)heads * head_dim || du_row_stride < (int64_t)heads * head_dim)
+    return set_error(HSTU_EINVAL, "norm_mul_bwd: a row stride is smaller than a row");
+  const bool silu = u_is_preactivation != 0;
   hipStream_t st = (hipStream_t)stream;
   const int width = group_norm ? heads : heads * head_dim;
   if (!dweight || !dbias) return set_error(HSTU_EINVAL, "norm_mul_bwd: dweight/dbias are required");
@@ -133,8 +163,8 @@ int hstu_norm_mul_dropout_bwd(const void* dy, const void* attn, const void* u, c
     return set_error(HSTU_EINVAL, "norm_mul_bwd: NULL tensor");
   const bool wd = norm_wide(heads * head_dim, attn, u, dy, dtype == HSTU_DTYPE_F32 ? 4 : 2) ||
                   norm_wide(heads * head_dim, dattn, du, nullptr, dtype == HSTU_DTYPE_F32 ? 4 : 2);
-#define NM_BWD(T) (wd ? nw4::nm_bwd<T>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, nw4::make_drop_ctx(dropout_ratio, seed), st) \
-                      : nw1::nm_bwd<T>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, nw1::make_drop_ctx(dropout_ratio, seed), st))
+#define NM_BWD(T) (wd ? nw4::nm_bwd<T>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, nw4::make_drop_ctx(dropout_ratio, seed), u_row_stride, du_row_stride, silu, st) \
+                      : nw1::nm_bwd<T>(dy, attn, u, weight, bias, mean, rstd, dattn, du, dweight, dbias, partial_ws, rows, heads, head_dim, group_norm, concat_ux, nw1::make_drop_ctx(dropout_ratio, seed), u_row_stride, du_row_stride, silu, st))
   DISPATCH_DTYPE(dtype, NM_BWD(bf16_t), NM_BWD(f16_t), NM_BWD(float));
 #undef NM_BWD
 }

@@ -6,6 +6,7 @@ _input_norm_bias, _output_weight, _output_norm_weight, _output_norm_bias``.
 """
 
 import abc
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -16,6 +17,8 @@ from generative_recommenders_amd.common import HammerModule
 from generative_recommenders_amd.ops import _launch
 from generative_recommenders_amd.ops.hstu_attention import delta_hstu_mha
 from generative_recommenders_amd.ops.hstu_compute import (
+    hstu_fused_layer,
+    hstu_fused_layer_applicable,
     hstu_compute_output,
     hstu_compute_uqvk,
     hstu_preprocess_and_attention,
@@ -83,6 +86,9 @@ class STULayer(STU):
         self._recompute_normed_x = config.recompute_normed_x
         self._recompute_uvqk = config.recompute_uvqk
         self._recompute_y = config.recompute_y
+        # MI355X: run forward() as ONE autograd node when no K/V goes to the cache (ops/hstu_compute.py::hstu_fused_layer);
+        # False (or HSTU_FUSE_LAYER=0) keeps the reference's two nodes -- same results
+        self.fuse_layer = os.environ.get("HSTU_FUSE_LAYER", "1") != "0"
         self._sort_by_length = config.sort_by_length
         self._contextual_seq_len = config.contextual_seq_len
 
@@ -162,6 +168,29 @@ class STULayer(STU):
     def forward(self, x: torch.Tensor, x_lengths: torch.Tensor, x_offsets: torch.Tensor, max_seq_len: int,
                 num_targets: torch.Tensor, max_kv_caching_len: int = 0,
                 kv_caching_lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if (self.fuse_layer and kv_caching_lengths is None and self._causal
+                and hstu_fused_layer_applicable(x, self._attention_dim, self._hidden_dim)):
+            # nothing to hand to the K/V cache: the whole layer as one autograd node (SiLU and the residual's gradient
+            # folded into the neighbouring row kernels; identical results)
+            with record_function("## stu_layer ##"):
+                out = hstu_fused_layer(
+                    x=x,
+                    input_norm_weight=self._input_norm_weight, input_norm_bias=self._input_norm_bias, input_norm_eps=1e-6,
+                    uvqk_weight=self._uvqk_weight, uvqk_bias=self._uvqk_beta,
+                    output_norm_weight=self._output_norm_weight, output_norm_bias=self._output_norm_bias,
+                    output_norm_eps=1e-6, output_weight=self._output_weight,
+                    num_heads=self._num_heads, attn_dim=self._attention_dim, hidden_dim=self._hidden_dim,
+                    max_seq_len=max_seq_len, seq_offsets=x_offsets, attn_alpha=self._attn_alpha,
+                    num_targets=num_targets if self._target_aware else None,
+                    max_attn_len=self._max_attn_len, contextual_seq_len=self._contextual_seq_len,
+                    dropout_ratio=self._output_dropout_ratio, training=self.training, concat_ux=True,
+                    group_norm=self._use_group_norm,
+                    recompute_uvqk_in_backward=self._recompute_uvqk,
+                    recompute_normed_x_in_backward=self._recompute_normed_x,
+                    recompute_y_in_backward=self._recompute_y, sort_by_length=self._sort_by_length)
+            self.update_kv_cache(max_seq_len=max_seq_len, seq_offsets=x_offsets, k=None, v=None,
+                                 max_kv_caching_len=max_kv_caching_len, kv_caching_lengths=kv_caching_lengths)
+            return out
         with record_function("## stu_preprocess_and_attention ##"):
             u, attn_output, k, v = hstu_preprocess_and_attention(
                 x=x,

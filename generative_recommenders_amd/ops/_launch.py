@@ -365,56 +365,71 @@ def layer_norm_fwd(x, weight, bias, eps):
     return y, mean, rstd
 
 
-def layer_norm_bwd(dy, x, weight, mean, rstd):
+def layer_norm_bwd(dy, x, weight, mean, rstd, dresidual=None):
+    """``dresidual``: a gradient that reaches x around the norm; added inside the kernel (dx = LN'(dy) + dresidual)."""
     dy, x = dy.contiguous(), x.contiguous()
+    dres = None if dresidual is None else dresidual.contiguous()
     rows, dim = x.shape
     dx = torch.empty_like(x)
     dw, db = _f32(dim, x.device), _f32(dim, x.device)
     ws = torch.empty(L.lib().hstu_norm_bwd_workspace_bytes(rows, dim), dtype=torch.uint8, device=x.device)
     w = weight.to(x.dtype).contiguous()
     with torch.cuda.device(x.device):
-        L.check(L.lib().hstu_layer_norm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(),
-                                            rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
-                                            ws.data_ptr(), rows, dim, L.torch_dtype_code(x.dtype),
-                                            L.current_stream_ptr(x.device)))
+        L.check(L.lib().hstu_layer_norm_bwd_residual(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(),
+                                                     rstd.data_ptr(), None if dres is None else dres.data_ptr(),
+                                                     dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, dim,
+                                                     L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
     return dx, dw, db
 
 
-def norm_mul_fwd(attn, u, weight, bias, eps, num_heads, head_dim, group_norm, concat_ux, dropout_ratio=0.0, seed=0):
+def _rows_view(t: torch.Tensor) -> torch.Tensor:
+    """a 2-D tensor whose rows are contiguous (a column slice of a wider buffer stays a view)"""
+    return t if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+
+
+def norm_mul_fwd(attn, u, weight, bias, eps, num_heads, head_dim, group_norm, concat_ux, dropout_ratio=0.0, seed=0,
+                 u_is_preactivation=False):
     """``dropout_ratio > 0``: the fused output-stage dropout (hstu_norm_mul_dropout_fwd); the mask is a function of
-    (seed, element index) -- pass the same seed to norm_mul_bwd (and to a recompute of y)."""
+    (seed, element index) -- pass the same seed to norm_mul_bwd (and to a recompute of y).
+    ``u_is_preactivation``: u is what goes INTO SiLU (e.g. the u slice of the uvqk buffer, read in place through its row
+    stride); the kernel applies SiLU on the fly (hstu_norm_mul_silu_fwd)."""
     L.require_gpu_tensor(attn, "attn")
-    attn, u = attn.contiguous(), u.contiguous()
+    attn, u = attn.contiguous(), _rows_view(u)
     rows, dim = attn.shape
     y = torch.empty((rows, 3 * dim if concat_ux else dim), dtype=attn.dtype, device=attn.device)
     ng = num_heads if group_norm else 1
     mean, rstd = _f32(rows * ng, attn.device), _f32(rows * ng, attn.device)
     w, b = weight.to(attn.dtype).contiguous(), bias.to(attn.dtype).contiguous()
     with torch.cuda.device(attn.device):
-        L.check(L.lib().hstu_norm_mul_dropout_fwd(attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
-                                                  mean.data_ptr(), rstd.data_ptr(), rows, num_heads, head_dim, float(eps),
-                                                  int(group_norm), int(concat_ux), float(dropout_ratio),
-                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, L.torch_dtype_code(attn.dtype),
-                                                  L.current_stream_ptr(attn.device)))
+        L.check(L.lib().hstu_norm_mul_silu_fwd(attn.data_ptr(), u.data_ptr(), u.stride(0), int(bool(u_is_preactivation)),
+                                               w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows,
+                                               num_heads, head_dim, float(eps), int(group_norm), int(concat_ux),
+                                               float(dropout_ratio), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                               L.torch_dtype_code(attn.dtype), L.current_stream_ptr(attn.device)))
     return y, mean, rstd
 
 
 def norm_mul_bwd(dy, attn, u, weight, bias, mean, rstd, num_heads, head_dim, group_norm, concat_ux, dropout_ratio=0.0,
-                 seed=0):
-    dy, attn, u = dy.contiguous(), attn.contiguous(), u.contiguous()
+                 seed=0, u_is_preactivation=False, du=None):
+    """``u_is_preactivation``: as in norm_mul_fwd; the returned du is then the gradient of the PRE-activation
+    (d u * SiLU').  ``du``: where to write it (a column slice of a wider buffer is fine: the u slice of d uvqk)."""
+    dy, attn, u = dy.contiguous(), attn.contiguous(), _rows_view(u)
     rows, dim = attn.shape
-    dattn, du = torch.empty_like(attn), torch.empty_like(u)
+    dattn = torch.empty_like(attn)
+    if du is None:
+        du = torch.empty((rows, dim), dtype=attn.dtype, device=attn.device)
+    assert du.shape == (rows, dim) and du.stride(1) == 1 and du.dtype == attn.dtype
     width = num_heads if group_norm else dim
     dw, db = _f32(width, attn.device), _f32(width, attn.device)
     ws = torch.empty(L.lib().hstu_norm_bwd_workspace_bytes(rows, dim), dtype=torch.uint8, device=attn.device)
     w, b = weight.to(attn.dtype).contiguous(), bias.to(attn.dtype).contiguous()
     with torch.cuda.device(attn.device):
-        L.check(L.lib().hstu_norm_mul_dropout_bwd(dy.data_ptr(), attn.data_ptr(), u.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                                  mean.data_ptr(), rstd.data_ptr(), dattn.data_ptr(), du.data_ptr(),
-                                                  dw.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, num_heads, head_dim,
-                                                  int(group_norm), int(concat_ux), float(dropout_ratio),
-                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, L.torch_dtype_code(attn.dtype),
-                                                  L.current_stream_ptr(attn.device)))
+        L.check(L.lib().hstu_norm_mul_silu_bwd(dy.data_ptr(), attn.data_ptr(), u.data_ptr(), u.stride(0),
+                                               int(bool(u_is_preactivation)), w.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), dattn.data_ptr(), du.data_ptr(), du.stride(0), dw.data_ptr(),
+                                               db.data_ptr(), ws.data_ptr(), rows, num_heads, head_dim, int(group_norm),
+                                               int(concat_ux), float(dropout_ratio), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                               L.torch_dtype_code(attn.dtype), L.current_stream_ptr(attn.device)))
     return dattn, du, dw, db
 
 

@@ -231,6 +231,157 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                 None, None, None, None, None, None, None)
 
 
+class _STULayerFunction(torch.autograd.Function):
+    """One whole STU layer -- LN -> UVQK GEMM -> jagged attention -> dropout([u, attn, u * Norm(attn)]) @ W_o + x
+    (stu.py:291-352 = hstu_preprocess_and_attention followed by hstu_compute_output) -- as ONE autograd node.  Compared
+    with the two nodes above, which mirror the reference's pair of Triton functions, three row passes disappear:
+
+    * SiLU(u): the output-stage kernels read the u slice of the uvqk buffer in place and apply SiLU on the fly, forward
+      and (recomputed) in backward; SiLU' is applied where d u is stored, straight into the u slice of d uvqk.  No
+      separate u tensor exists, so none is saved for backward either (one (sum L, H hidden) tensor per layer less).
+    * the residual: the gradient that reaches x around the layer is added inside the layer-norm backward kernel instead
+      of by autograd's accumulation of two gradients.
+
+    Everything is rounded where the separate passes would have rounded it: with 16-bit activations outputs and gradients
+    are bit-identical to the two-node path, in fp32 equal to an ulp or two
+    (tests/test_compute_gpu.py::test_fused_layer_node_matches_two_nodes)."""
+
+    @staticmethod
+    def forward(ctx, x, in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight, seq_offsets, num_targets,
+                in_eps, out_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
+                recompute_uvqk, recompute_normed_x, recompute_y, concat_ux, group_norm, dropout_ratio, seed, user_order):
+        ctx.param_dtypes = tuple(t.dtype for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
+        in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight = (
+            _cast(t, x.dtype) for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
+        normed_x, mean, rstd = _launch.layer_norm_fwd(x, in_nw, in_nb, in_eps)
+        uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
+        hv, ha = hidden_dim * num_heads, attn_dim * num_heads
+        v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
+        q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, num_heads, attn_dim)
+        k = uvqk[:, 2 * hv + ha :].view(-1, num_heads, attn_dim)
+        attn = _launch.attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, attn_alpha, 1.0 / max_seq_len,
+                                max_attn_len, contextual_seq_len, 0, user_order=user_order).view(-1, hv)
+        y, omean, orstd = _launch.norm_mul_fwd(attn, uvqk[:, :hv], out_nw, out_nb, out_eps, num_heads, hidden_dim, group_norm,
+                                               concat_ux, dropout_ratio, seed, u_is_preactivation=True)
+        out = torch.addmm(x, y, output_weight)
+        saved = [x, in_nw, in_nb, mean, rstd, uvqk_weight, uvqk_bias, seq_offsets, attn, out_nw, out_nb, omean, orstd,
+                 output_weight]
+        ctx.has_targets = num_targets is not None
+        if ctx.has_targets:
+            saved.append(num_targets)
+        ctx.keep = (not recompute_normed_x, not recompute_uvqk, not recompute_y)
+        for keep, t in zip(ctx.keep, (normed_x, uvqk, y)):
+            if keep:
+                saved.append(t)
+        ctx.save_for_backward(*saved)
+        ctx.user_order = user_order
+        ctx.meta = (in_eps, out_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len,
+                    contextual_seq_len, concat_ux, group_norm, dropout_ratio, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = list(ctx.saved_tensors)
+        x, nw, nb, mean, rstd, W, beta, seq_offsets, attn, onw, onb, omean, orstd, Wo = saved[:14]
+        rest = saved[14:]
+        num_targets = rest.pop(0) if ctx.has_targets else None
+        normed_x = rest.pop(0) if ctx.keep[0] else None
+        uvqk = rest.pop(0) if ctx.keep[1] else None
+        y = rest.pop(0) if ctx.keep[2] else None
+        in_eps, out_eps, H, A, Hd, N, alpha, w, c, cat, gn, p_drop, seed = ctx.meta
+        if normed_x is None:
+            normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, in_eps)
+        if uvqk is None:
+            uvqk = torch.addmm(beta, normed_x, W)
+        hv, ha = Hd * H, A * H
+        u_pre = uvqk[:, :hv]
+        if y is None:
+            y, _, _ = _launch.norm_mul_fwd(attn, u_pre, onw, onb, out_eps, H, Hd, gn, cat, p_drop, seed,
+                                           u_is_preactivation=True)
+        dt = ctx.param_dtypes
+        # ---- output stage (dout is also the gradient of the residual)
+        dout = dout.contiguous()
+        dy = torch.mm(dout, Wo.t())
+        dWo = weight_grad_mm(y, dout, out_dtype=dt[6])
+        del y
+        duvqk = torch.empty_like(uvqk)
+        dattn, _, donw, donb = _launch.norm_mul_bwd(dy, attn, u_pre, onw, onb, omean, orstd, H, Hd, gn, cat, p_drop, seed,
+                                                    u_is_preactivation=True, du=duvqk[:, :hv])
+        del dy
+        # ---- attention
+        v = uvqk[:, hv : 2 * hv].view(-1, H, Hd)
+        q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
+        k = uvqk[:, 2 * hv + ha :].view(-1, H, A)
+        dv = duvqk[:, hv : 2 * hv].view(-1, H, Hd)
+        dq = duvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
+        dk = duvqk[:, 2 * hv + ha :].view(-1, H, A)
+        _launch.attn_bwd(dattn.view(-1, H, Hd), q, k, v, seq_offsets, num_targets, N, alpha, 1.0 / N, w, c, 0,
+                         dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
+        # ---- projections and the input norm (+ the residual's gradient, inside the kernel)
+        d_normed = torch.mm(duvqk, W.t())
+        dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
+        dbeta = duvqk.sum(dim=0, dtype=torch.float32 if dt[3] == torch.float32 else None)
+        dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd, dresidual=dout)
+        return (dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, dbeta.to(dt[3]), donw.to(dt[4]), donb.to(dt[5]), dWo) + (None,) * 19
+
+
+def hstu_fused_layer_applicable(x: torch.Tensor, attn_dim: int, hidden_dim: int) -> bool:
+    """the single-node layer needs the head slices of the fused uvqk buffer 16-byte aligned (as the fused preprocess node)"""
+    es = x.element_size()
+    return x.is_cuda and (attn_dim * es) % 16 == 0 and (hidden_dim * es) % 16 == 0
+
+
+def hstu_fused_layer(
+    x: torch.Tensor,
+    input_norm_weight: torch.Tensor,
+    input_norm_bias: torch.Tensor,
+    input_norm_eps: float,
+    uvqk_weight: torch.Tensor,
+    uvqk_bias: torch.Tensor,
+    output_norm_weight: torch.Tensor,
+    output_norm_bias: torch.Tensor,
+    output_norm_eps: float,
+    output_weight: torch.Tensor,
+    num_heads: int,
+    attn_dim: int,
+    hidden_dim: int,
+    max_seq_len: int,
+    seq_offsets: torch.Tensor,
+    attn_alpha: float,
+    num_targets: Optional[torch.Tensor],
+    max_attn_len: int,
+    contextual_seq_len: int,
+    dropout_ratio: float,
+    training: bool,
+    concat_ux: bool,
+    group_norm: bool,
+    recompute_uvqk_in_backward: bool,
+    recompute_normed_x_in_backward: bool,
+    recompute_y_in_backward: bool,
+    sort_by_length: bool,
+) -> torch.Tensor:
+    """``hstu_compute_output(*hstu_preprocess_and_attention(x, ...)[:2], x, ...)`` -- the body of STULayer.forward
+    (stu.py:291-352) -- as one autograd node (_STULayerFunction): same arguments, same results.  Not in the
+    reference's API; STULayer uses it when no K/V has to be handed to the cache."""
+    torch._assert(max_seq_len > 0, "max_seq_len must be larger than 0")
+    torch._assert(x.dim() == 2, "x must be 2-D")
+    torch._assert(x.shape[1] == uvqk_weight.shape[0], "x.shape[1] must equal uvqk_weight.shape[0]")
+    torch._assert(
+        uvqk_weight.shape[1] == 2 * num_heads * (hidden_dim + attn_dim),
+        "uvqk_weight.shape[1] must equal 2 * num_heads * (hidden_dim + attn_dim)",
+    )
+    torch._assert(hstu_fused_layer_applicable(x, attn_dim, hidden_dim), "head dims must be 16-byte multiples")
+    p_drop = float(dropout_ratio) if training else 0.0
+    torch._assert(0.0 <= p_drop < 1.0, "dropout_ratio must be in [0, 1)")
+    seed = draw_dropout_seed() if p_drop > 0.0 else 0
+    order = _launch.length_order(_launch._idx(seq_offsets)) if sort_by_length and seq_offsets.numel() > 2 else None
+    return _STULayerFunction.apply(
+        x, input_norm_weight, input_norm_bias, uvqk_weight, uvqk_bias, output_norm_weight, output_norm_bias, output_weight,
+        seq_offsets, num_targets, input_norm_eps, output_norm_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha,
+        max_attn_len, contextual_seq_len, recompute_uvqk_in_backward, recompute_normed_x_in_backward,
+        recompute_y_in_backward, concat_ux, group_norm, p_drop, seed, order)
+
+
 def hstu_preprocess_and_attention(
     x: torch.Tensor,
     norm_weight: torch.Tensor,

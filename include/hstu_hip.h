@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 6
+#define HSTU_ABI_VERSION 7
 
 enum {
   HSTU_OK = 0,
@@ -218,6 +218,12 @@ int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight,
                         const float* mean, const float* rstd, void* dx,
                         float* dweight, float* dbias, float* partial_ws,
                         int64_t rows, int32_t dim, int dtype, void* stream);
+/* ABI v7: dx = LayerNorm'(dy) + dresidual -- the gradient that reaches x around the norm (the STU layer's residual,
+ * stu.py:340-351) added inside the kernel instead of by a separate pass; dresidual (rows, dim) in `dtype`, may be NULL. */
+int hstu_layer_norm_bwd_residual(const void* dy, const void* x, const void* weight,
+                                 const float* mean, const float* rstd, const void* dresidual,
+                                 void* dx, float* dweight, float* dbias, float* partial_ws,
+                                 int64_t rows, int32_t dim, int dtype, void* stream);
 size_t hstu_norm_bwd_workspace_bytes(int64_t rows, int32_t dim);
 
 /*
@@ -254,6 +260,23 @@ int hstu_norm_mul_dropout_bwd(const void* dy, const void* attn, const void* u, c
                               float* partial_ws, int64_t rows, int32_t heads, int32_t head_dim,
                               int group_norm, int concat_ux, float dropout_ratio, uint64_t seed,
                               int dtype, void* stream);
+
+/* ABI v7: the same with u given by rows `u_row_stride` elements apart and, when u_is_preactivation != 0, as the
+ * PRE-activation of SiLU (the u slice of the uvqk buffer): the kernels apply SiLU on the fly, rounded to `dtype` where
+ * hstu_silu_fwd would have stored it, and the backward multiplies d u by SiLU' and writes rows `du_row_stride` apart
+ * (the u slice of the d uvqk buffer) -- hstu_silu_fwd / hstu_silu_bwd fused away, results bit-identical to the
+ * separate calls.  Replaces the F.silu(u) of hstu_compute_uqvk (ops/hstu_compute.py:85) next to
+ * _group_norm_mul_dropout_fwd/_bwd inside one STU layer. */
+int hstu_norm_mul_silu_fwd(const void* attn, const void* u, int64_t u_row_stride, int u_is_preactivation,
+                           const void* weight, const void* bias, void* y, float* mean, float* rstd,
+                           int64_t rows, int32_t heads, int32_t head_dim, float eps, int group_norm,
+                           int concat_ux, float dropout_ratio, uint64_t seed, int dtype, void* stream);
+int hstu_norm_mul_silu_bwd(const void* dy, const void* attn, const void* u, int64_t u_row_stride,
+                           int u_is_preactivation, const void* weight, const void* bias,
+                           const float* mean, const float* rstd, void* dattn, void* du,
+                           int64_t du_row_stride, float* dweight, float* dbias, float* partial_ws,
+                           int64_t rows, int32_t heads, int32_t head_dim, int group_norm, int concat_ux,
+                           float dropout_ratio, uint64_t seed, int dtype, void* stream);
 
 /* u = silu(u) in place on the leading `u_cols` columns of each row of a
  * (rows, row_stride) matrix, and its backward (du *= silu'(u_pre)); the SiLU-on-u

@@ -229,6 +229,53 @@ def test_stu_stack_golden_fwd_bwd(flags):
         _close(p.grad, c["g:" + name], what="grad " + name, rtol=2e-3, atol_scale=3e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("group_norm", [False, True])
+@pytest.mark.parametrize("recompute", [True, False])
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_fused_layer_node_matches_two_nodes(dtype, group_norm, recompute, dropout):
+    """STULayer.forward as ONE autograd node (SiLU folded into the output-stage kernels, the residual's gradient into the
+    layer-norm backward) against the reference-shaped pair of nodes: the same kernels' arithmetic rounded at the same
+    places, so the output and every gradient must agree bit for bit (16-bit activations; to an ulp or two in fp32) -- fp32 master parameters next to `dtype` activations,
+    targets, sort_by_length, with the fused dropout (same seed) and all recompute flags on or off."""
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig
+
+    D, H, Hd, A, N, B = 256, 4, 64, 64, 96, 7
+    g = torch.Generator().manual_seed(11)
+    lengths = torch.randint(1, N + 1, (B,), generator=g)
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lengths, 0)
+    nt = torch.minimum(torch.randint(0, 9, (B,), generator=g), lengths)
+    x0 = torch.randn(int(off[-1]), D, generator=g)
+    gy = torch.randn(int(off[-1]), D, generator=g)
+    torch.manual_seed(3)
+    layer = STULayer(STULayerConfig(embedding_dim=D, num_heads=H, hidden_dim=Hd, attention_dim=A, output_dropout_ratio=dropout,
+                                    causal=True, target_aware=True, max_attn_len=None, attn_alpha=None, use_group_norm=group_norm,
+                                    recompute_normed_x=recompute, recompute_uvqk=recompute, recompute_y=recompute,
+                                    sort_by_length=True, contextual_seq_len=0)).to(DEV).train()
+    with torch.no_grad():
+        for p in layer.parameters():      # the norm weights start at exactly 1 / 0: make every gradient path non-trivial
+            p.add_(0.05 * torch.randn(p.shape, generator=g).to(DEV))
+    res = {}
+    for fused in (True, False):
+        layer.fuse_layer = fused
+        layer.zero_grad(set_to_none=True)
+        x = x0.to(DEV).to(dtype).requires_grad_()
+        torch.manual_seed(17)             # the dropout seed is drawn from torch's CPU generator
+        y = layer(x=x, x_lengths=lengths.to(DEV), x_offsets=off.to(DEV), max_seq_len=N, num_targets=nt.to(DEV))
+        y.backward(gy.to(DEV).to(dtype))
+        res[fused] = [y.detach(), x.grad] + [p.grad for p in layer.parameters()]
+    names = ["y", "dx"] + [n for n, _ in layer.named_parameters()]
+    for n, a, b in zip(names, res[True], res[False]):
+        assert a.dtype == b.dtype and a.shape == b.shape, n
+        if dtype == torch.float32:      # (fp32 rows: an fma contracted differently here or there -- an ulp of u, carried through the GEMMs)
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()), msg=lambda m: f"{n}: {m}")
+        else:
+            assert torch.equal(a, b), f"{n}: fused node differs from the two-node path (max abs diff {(a.float() - b.float()).abs().max().item():.3e})"
+    if dropout > 0:
+        assert (res[True][0] != 0).any()
+
+
 def test_stu_cached_forward_equals_full_forward():
     """prefill + cached_forward == the delta rows of a full forward
     (modules/tests/stu_test.py:341-457: every delta row is a target, same max_seq_len in

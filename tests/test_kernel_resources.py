@@ -71,6 +71,9 @@ def test_no_kernel_spills_or_uses_scratch():
     # times the pieces per lane; their backward kernels spill.  They exist so that H x hidden_dim > 1024 works at all (the
     # reference's kernels take any D); every BASELINE configuration (<= 1024) runs the narrow instances, which may not spill.
     accepted = accepted + ("N4hstu3nw4",)
+    # u * GroupNorm(attn) backward with SiLU applied on the fly (single-chunk rows): 98 registers, asked to fit the 96 of a
+    # fifth wave per SIMD -- 2 spilled registers, measured 4 % faster than 4 waves without (profiles/r03_ab_row_passes_silu.txt)
+    bounded.update({"norm_mul_bwd_gn_kernelIDF16bLi8ELi1ELb1E": 2, "norm_mul_bwd_gn_kernelIDF16_Li8ELi1ELb1E": 2})
     bad = {k: v for k, v in ks.items() if (v["spill"] or v["scratch"]) and "hstu" in k and not any(a in k for a in accepted)
            and not any(b in k and v["spill"] <= n for b, n in bounded.items())}
     assert not bad, f"kernels with register spills / scratch: {bad}"

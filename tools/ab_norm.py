@@ -45,6 +45,7 @@ def main():
     lb = torch.randn(D, device=dev, dtype=bf, generator=gen)
     uvqk = torch.randn(R, 4 * D, device=dev, dtype=bf, generator=gen)
     duvqk = torch.randn(R, 4 * D, device=dev, dtype=bf, generator=gen)
+    dy3 = torch.randn(R, 3 * D, device=dev, dtype=bf, generator=gen)
     st = L.current_stream_ptr(torch.device(dev))
     code = L.torch_dtype_code(bf)
     seed = 0x1234567890ABCDEF
@@ -57,7 +58,8 @@ def main():
                  dw=torch.empty(H, device=dev), db=torch.empty(H, device=dev), ws=torch.empty(ws_bytes // 4, device=dev),
                  ly=torch.empty(R, D, device=dev, dtype=bf), lmean=torch.empty(R, device=dev), lrstd=torch.empty(R, device=dev),
                  ldx=torch.empty(R, D, device=dev, dtype=bf), ldw=torch.empty(D, device=dev), ldb=torch.empty(D, device=dev),
-                 su=torch.empty(R, D, device=dev, dtype=bf), sd=torch.empty(R, 4 * D, device=dev, dtype=bf))
+                 su=torch.empty(R, D, device=dev, dtype=bf), sd=torch.empty(R, 4 * D, device=dev, dtype=bf),
+                 y3=torch.empty(R, 3 * D, device=dev, dtype=bf))
         P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         F = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_float))  # noqa: E731
         calls = {
@@ -66,6 +68,12 @@ def main():
             "norm_mul_bwd": (lambda: lib.hstu_norm_mul_dropout_bwd(P(dy), P(attn), P(u), P(w), P(b), F(o["mean"]), F(o["rstd"]), P(o["dattn"]),
                                                                      P(o["du"]), F(o["dw"]), F(o["db"]), F(o["ws"]), R, H, d, 1, 0,
                                                                      C.c_float(a.dropout), C.c_uint64(seed), code, st), 5 * R * D * 2),
+            # the layer's own configuration: [u, attn, y] concat, u read in place from the uvqk buffer with SiLU applied on the fly
+            "nm_silu_cat_fwd": (lambda: lib.hstu_norm_mul_silu_fwd(P(attn), P(uvqk), 4 * D, 1, P(w), P(b), P(o["y3"]), F(o["mean"]), F(o["rstd"]), R, H, d,
+                                                                     C.c_float(1e-5), 1, 1, C.c_float(a.dropout), C.c_uint64(seed), code, st), 5 * R * D * 2),
+            "nm_silu_cat_bwd": (lambda: lib.hstu_norm_mul_silu_bwd(P(dy3), P(attn), P(uvqk), 4 * D, 1, P(w), P(b), F(o["mean"]), F(o["rstd"]), P(o["dattn"]),
+                                                                     P(o["sd"]), 4 * D, F(o["dw"]), F(o["db"]), F(o["ws"]), R, H, d, 1, 1,
+                                                                     C.c_float(a.dropout), C.c_uint64(seed), code, st), 7 * R * D * 2),
             "layer_norm_fwd": (lambda: lib.hstu_layer_norm_fwd(P(attn), P(lw), P(lb), P(o["ly"]), F(o["lmean"]), F(o["lrstd"]), R, D,
                                                                  C.c_float(1e-5), code, st), 2 * R * D * 2),
             "layer_norm_bwd": (lambda: lib.hstu_layer_norm_bwd(P(dy), P(attn), P(lw), F(o["lmean"]), F(o["lrstd"]), P(o["ldx"]), F(o["ldw"]),
@@ -79,7 +87,7 @@ def main():
     for path in a.libs:
         lib = C.CDLL(os.path.abspath(path))
         for n in ("hstu_norm_mul_dropout_fwd", "hstu_norm_mul_dropout_bwd", "hstu_layer_norm_fwd", "hstu_layer_norm_bwd", "hstu_silu_fwd",
-                  "hstu_silu_bwd"):
+                  "hstu_silu_bwd", "hstu_norm_mul_silu_fwd", "hstu_norm_mul_silu_bwd"):
             f = getattr(lib, n)
             f.restype = C.c_int
             f.argtypes = getattr(base_lib, n).argtypes
@@ -104,7 +112,7 @@ def main():
                 torch.cuda.synchronize()
                 if rep:
                     times[(ln, n)].append(e0.elapsed_time(e1) / a.launches)
-    outs_of = {"norm_mul_fwd": ("y", "mean", "rstd"), "norm_mul_bwd": ("dattn", "du", "dw", "db"), "layer_norm_fwd": ("ly", "lmean", "lrstd"),
+    outs_of = {"nm_silu_cat_fwd": ("y3",), "nm_silu_cat_bwd": ("dattn",), "norm_mul_fwd": ("y", "mean", "rstd"), "norm_mul_bwd": ("dattn", "du", "dw", "db"), "layer_norm_fwd": ("ly", "lmean", "lrstd"),
                "layer_norm_bwd": ("ldx", "ldw", "ldb"), "silu_fwd": ("su",), "silu_bwd": ("sd",)}
     base_o = libs[0][2]
     print(f"rows {R}, {H} heads x {d}, bf16, dropout {a.dropout}")
