@@ -9,6 +9,7 @@ autograd nodes follow the saved-tensor / recompute contract of the reference's T
 SURVEY.md App. F): results are identical whichever recompute flags are chosen.
 """
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -36,7 +37,7 @@ def hstu_compute_uqvk(
     del kernel
     norm_weight, norm_bias, uvqk_weight, uvqk_bias = (t.to(x.dtype) for t in (norm_weight, norm_bias, uvqk_weight, uvqk_bias))
     normed_x = layer_norm(x, weight=norm_weight, bias=norm_bias, eps=norm_eps)
-    uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
+    uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)        # (autograd's own node: the reference layout)
     u, v, q, k = torch.split(
         uvqk, [hidden_dim * num_heads, hidden_dim * num_heads, attn_dim * num_heads, attn_dim * num_heads], dim=1
     )
@@ -63,6 +64,19 @@ def draw_dropout_seed() -> int:
     """The seed of one fused-dropout call, drawn the way the reference draws it (triton_hstu_linear.py:376-377: torch's
     default CPU generator, no device sync) -- ``torch.manual_seed`` makes a run reproducible."""
     return int(torch.randint(low=0, high=2**62, size=(1,), dtype=torch.int64).item())
+
+
+# The UVQK projection as ``linear(x, W^T-copy, b)``: hipBLASLt's kernels for a K-contiguous weight run this shape (K = 512, N =
+# 2048) at 797 TFLOP/s against 737 for ``addmm(b, x, W)`` with the reference's (in, out) layout (tools/bench_gemm_layout.py,
+# profiles/r03_gemm_layout.txt).  The transposed copy is a 1 M-element pass next to the parameter cast; HSTU_UVQK_LINEAR=0
+# keeps addmm.
+_UVQK_LINEAR = os.environ.get("HSTU_UVQK_LINEAR", "1") != "0"
+
+
+def _uvqk_gemm(normed_x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    if _UVQK_LINEAR and normed_x.is_cuda:
+        return torch.nn.functional.linear(normed_x, weight.t().contiguous(), bias)
+    return torch.addmm(bias, normed_x, weight)
 
 
 def _cast(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -173,7 +187,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         norm_weight, norm_bias, uvqk_weight, uvqk_bias = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_weight,
                                                                                        uvqk_bias))
         normed_x, mean, rstd = _launch.layer_norm_fwd(x, norm_weight, norm_bias, norm_eps)
-        uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
+        uvqk = _uvqk_gemm(normed_x, uvqk_weight, uvqk_bias)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
         u_pre = uvqk[:, :hv]
         v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
@@ -210,7 +224,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         if normed_x is None:
             normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, eps)
         if uvqk is None:
-            uvqk = torch.addmm(beta, normed_x, W)
+            uvqk = _uvqk_gemm(normed_x, W, beta)
         hv, ha = Hd * H, A * H
         v = uvqk[:, hv : 2 * hv].view(-1, H, Hd)
         q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
@@ -254,7 +268,7 @@ class _STULayerFunction(torch.autograd.Function):
         in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight = (
             _cast(t, x.dtype) for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
         normed_x, mean, rstd = _launch.layer_norm_fwd(x, in_nw, in_nb, in_eps)
-        uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
+        uvqk = _uvqk_gemm(normed_x, uvqk_weight, uvqk_bias)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
         v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
         q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, num_heads, attn_dim)
@@ -292,7 +306,7 @@ class _STULayerFunction(torch.autograd.Function):
         if normed_x is None:
             normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, in_eps)
         if uvqk is None:
-            uvqk = torch.addmm(beta, normed_x, W)
+            uvqk = _uvqk_gemm(normed_x, W, beta)
         hv, ha = Hd * H, A * H
         u_pre = uvqk[:, :hv]
         if y is None:
