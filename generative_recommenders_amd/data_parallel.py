@@ -161,6 +161,7 @@ class GradientAllReducer:
     def _reset(self) -> None:
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
+        self._staged = [[] for _ in self.buckets]
 
     def _bucket_flat(self, bi: int, like: torch.Tensor) -> torch.Tensor:
         n = sum(p.numel() for p in self.buckets[bi])
@@ -175,11 +176,19 @@ class GradientAllReducer:
         flat = self._bucket_flat(bi, p.grad)
         view = flat[o : o + p.numel()].view_as(p)
         if p.grad.data_ptr() != view.data_ptr():
-            view.copy_(p.grad)
-            p.grad = view          # the reduced values appear in p.grad without a copy back
+            self._staged[bi].append((p, view))       # moved into the bucket when its last gradient is in: ONE multi-tensor copy
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and dist.is_initialized() and dist.get_world_size() > 1:
-            self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        if self._pending[bi] == 0:
+            staged = self._staged[bi]
+            if staged:
+                # (a hipMemcpyDtoD per parameter costs ~15 us each on the compute stream, 24 per step of a 3-layer stack;
+                # _foreach_copy_ is one kernel launch per bucket)
+                torch._foreach_copy_([v for _, v in staged], [q.grad for q, _ in staged])
+                for q, v in staged:
+                    q.grad = v         # the reduced values appear in p.grad without a copy back
+                self._staged[bi] = []
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def remove_hooks(self) -> None:
         for h in self._hooks:
@@ -194,9 +203,16 @@ class GradientAllReducer:
                     work.wait()
                     if self.average:
                         self._flat[bi].div_(world)
-                elif world > 1 and self._pending[bi] != len(self.buckets[bi]):
+                elif self._pending[bi] != len(self.buckets[bi]) and self._pending[bi] != 0:
                     # some parameters of the bucket got no gradient this step: reduce what is there (zeros for the rest)
                     flat = self._flat[bi]
+                    staged = self._staged[bi]
+                    if staged:
+                        torch._foreach_copy_([v for _, v in staged], [q.grad for q, _ in staged])
+                        for q, v in staged:
+                            q.grad = v
+                    if world == 1:
+                        continue
                     for p in self.buckets[bi]:
                         if p.grad is None:
                             b2, o = self._slot[id(p)]
