@@ -313,7 +313,7 @@ def layer_section(args, rank, world, device):
     gy = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen)
     nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
 
-    def timed(recompute, dropout):
+    def timed(recompute, dropout, fuse=True):
         """recompute=True: the reference's STULayerConfig defaults (normed x, uvqk and y recomputed in the backward --
         a memory saving sized for 80 GB parts); False: everything kept (3 layers x 1024 users: 2.4 GB of 288).
         dropout: output_dropout_ratio of the layers (DLRM-v3 trains with hstu_linear_dropout_rate = 0.1,
@@ -323,6 +323,8 @@ def layer_section(args, rank, world, device):
                                                   output_dropout_ratio=dropout, use_group_norm=True, recompute_normed_x=recompute,
                                                   recompute_uvqk=recompute, recompute_y=recompute)) for _ in range(3)]).to(device)
         stack.train()
+        for layer in stack._stu_layers:
+            layer.fuse_layer = fuse        # True: the layer as one autograd node (default); False: the reference's two nodes
         # one bucket per layer, its all-reduce launched from inside backward when the layer's last gradient is in
         reducer = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in stack._stu_layers], overlap=True)
 
@@ -356,6 +358,7 @@ def layer_section(args, rank, world, device):
         tunable.set_max_tuning_duration(200)
     elapsed_keep, _ = timed(False, p_drop)
     elapsed_nodrop, _ = timed(True, 0.0)
+    elapsed_two, _ = timed(True, p_drop, fuse=False)
     elapsed, stack = timed(True, p_drop)
     nparams = sum(p.numel() for p in stack.parameters())
     gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
@@ -364,7 +367,10 @@ def layer_section(args, rank, world, device):
                 gemm_selection="TunableOp" if getattr(args, "layer_tunableop", False) else "hipBLASLt heuristic (default)",
                 config=f"3 STU layers D=512, 4 heads of 128, group norm, targets; training mode, output_dropout_ratio={p_drop} "
                        f"(fused, mask regenerated in backward), recompute normed_x / uvqk / y in backward; gradient all-reduce: "
-                       f"one bucket per layer launched from backward hooks",
+                       f"one bucket per layer launched from backward hooks; each layer ONE autograd node (SiLU and the residual's "
+                       f"gradient inside the neighbouring row kernels)",
+                two_node_layers=dict(ms_per_step=elapsed_two / args.layer_steps * 1e3,
+                                     user_seqs_per_s=world * B * args.layer_steps / elapsed_two),
                 dropout_off=dict(ms_per_step=elapsed_nodrop / args.layer_steps * 1e3,
                                  user_seqs_per_s=world * B * args.layer_steps / elapsed_nodrop),
                 allreduce_bytes=nparams * 4,
