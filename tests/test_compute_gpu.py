@@ -194,6 +194,67 @@ def test_compute_output_shape_of_reference_test_bf16():
     _close(y, ref, rtol=3e-2, atol_scale=1e-2, what="bf16 output")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("heads,hd,group_norm", [(4, 128, True), (4, 64, False), (3, 40, True), (2, 24, False), (8, 256, True)])
+@pytest.mark.parametrize("concat", [False, True])
+def test_norm_mul_silu_matches_separate_kernels(dtype, heads, hd, group_norm, concat):
+    """hstu_norm_mul_silu_fwd / _bwd (ABI v7: u read in place, as the pre-activation slice of a wider buffer, SiLU and SiLU'
+    applied inside) against hstu_silu_fwd -> hstu_norm_mul_dropout_fwd and hstu_norm_mul_dropout_bwd -> hstu_silu_bwd on
+    the same inputs, with dropout: every kernel variant (group-norm fast path single / multi chunk, generic vector and
+    scalar paths, the wide instance), rows that are not 16-byte multiples (40, 24 elements per head: scalar path)."""
+    from generative_recommenders_amd.ops import _launch
+
+    rows, dim = 333, heads * hd
+    g = torch.Generator().manual_seed(5)
+    buf = torch.randn(rows, 4 * dim + 8, generator=g).to(DEV).to(dtype)       # u = columns [8, 8 + dim) of a wider buffer
+    u_pre = buf[:, 8:8 + dim]
+    attn = torch.randn(rows, dim, generator=g).to(DEV).to(dtype)
+    width = heads if group_norm else dim
+    w = (1 + 0.1 * torch.randn(width, generator=g)).to(DEV).to(dtype)
+    b = (0.1 * torch.randn(width, generator=g)).to(DEV).to(dtype)
+    dy = torch.randn(rows, 3 * dim if concat else dim, generator=g).to(DEV).to(dtype)
+    p, seed = 0.25, 0x1234567
+    # separate passes
+    u = _launch.silu_fwd(u_pre)
+    y0, m0, r0 = _launch.norm_mul_fwd(attn, u, w, b, 1e-6, heads, hd, group_norm, concat, p, seed)
+    dattn0, du0, dw0, db0 = _launch.norm_mul_bwd(dy, attn, u, w, b, m0, r0, heads, hd, group_norm, concat, p, seed)
+    dpre0 = _launch.silu_bwd(du0, u_pre)
+    # fused
+    y1, m1, r1 = _launch.norm_mul_fwd(attn, u_pre, w, b, 1e-6, heads, hd, group_norm, concat, p, seed, u_is_preactivation=True)
+    dbuf = torch.full_like(buf, 7.0)
+    dattn1, dpre1, dw1, db1 = _launch.norm_mul_bwd(dy, attn, u_pre, w, b, m1, r1, heads, hd, group_norm, concat, p, seed,
+                                                   u_is_preactivation=True, du=dbuf[:, 8:8 + dim])
+    exact = dtype != torch.float32          # fp32: an fma may be contracted differently in the fused kernel
+    for name, a, c in (("y", y1, y0), ("mean", m1, m0), ("rstd", r1, r0), ("dattn", dattn1, dattn0), ("d u_pre", dpre1, dpre0)):
+        if exact:
+            assert torch.equal(a, c), f"{name}: max abs diff {(a.float() - c.float()).abs().max().item():.3e}"
+        else:
+            torch.testing.assert_close(a, c, rtol=2e-6, atol=2e-6 * float(c.abs().max()), msg=lambda m_: f"{name}: {m_}")
+    torch.testing.assert_close(dw1, dw0, rtol=1e-5, atol=1e-5 * float(dw0.abs().max()))
+    torch.testing.assert_close(db1, db0, rtol=1e-5, atol=1e-5 * float(db0.abs().max()))
+    assert dpre1.data_ptr() == dbuf[:, 8:8 + dim].data_ptr()                       # written in place ...
+    assert bool((dbuf[:, :8] == 7.0).all()) and bool((dbuf[:, 8 + dim:] == 7.0).all())   # ... and nothing around it
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,dim", [(257, 512), (64, 100), (33, 2048)])
+def test_layer_norm_bwd_residual(rows, dim, dtype):
+    """hstu_layer_norm_bwd_residual: dx = LayerNorm'(dy) + dresidual in one pass == the two-pass result, rounded the same way."""
+    from generative_recommenders_amd.ops import _launch
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, dim, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(rows, dim, generator=g).to(DEV).to(dtype)
+    dres = torch.randn(rows, dim, generator=g).to(DEV).to(dtype)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(DEV).to(dtype)
+    b = torch.zeros(dim, device=DEV, dtype=dtype)
+    _, mean, rstd = _launch.layer_norm_fwd(x, w, b, 1e-6)
+    dx0, dw0, db0 = _launch.layer_norm_bwd(dy, x, w, mean, rstd)
+    dx1, dw1, db1 = _launch.layer_norm_bwd(dy, x, w, mean, rstd, dresidual=dres)
+    assert torch.equal(dx1, dx0 + dres)
+    assert torch.equal(dw1, dw0) and torch.equal(db1, db0)
+
+
 def _load_stack(c, dtype=torch.float32, **cfg_over):
     from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig, STUStack
 
