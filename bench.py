@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- HSTU attention fwd+bwd throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload M-full|M-jag|M-targets|C2|C3|C4|C5]
+    python bench.py --gpus N --steps K --warmup W [--workload M-full|M-jag|M-targets|C2|C3|C3-bias|C4|C5]
 
 A *step* is one pass of the hot path -- hstu attention forward + backward through the C ABI (libhstu_hip.so) -- over one
 batch of synthetic jagged user sequences that is already resident in HBM.  Default workload = the metric shape M
@@ -51,6 +51,8 @@ WORKLOADS = {
     "M-targets": (200, 4, 128, 8192, "M-jag lengths, num_targets = randint(1, 21) (general mask algebra)"),
     "C2": (211, 4, 64, 8192, "ML-20M shape, research path: relative position + time-bucket bias inside the kernels, L = randint(1, 212)"),
     "C3": (61, 4, 16, 8192, "Amazon-Books shape, long-tail lengths: randint(0, 30), 5 % of the users at the full 61"),
+    "C3-bias": (61, 4, 16, 8192, "Amazon-Books shape on the research path (the configuration the reference trains it with): relative position + time-bucket "
+                                   "bias inside the short-sequence kernels, lengths as C3"),
     "C4": (200, 4, 64, 1024, "one rank's shard (1024 users) of the DP-8 synthetic ML-3B batch, M-jag lengths"),
     "C5": (8192, 16, 64, 32, "HSTU-large M-FALCON microbatch: 256 candidates per user against L = randint(7372, 8192) cached rows, forward only, 24 layers back to back"),
 }
@@ -61,7 +63,7 @@ def make_lengths(workload, B, N, gen, device):
         return torch.full((B,), N, dtype=torch.int64, device=device)
     if workload == "C2":
         return torch.randint(1, N + 1, (B,), generator=gen, device=device, dtype=torch.int64)
-    if workload == "C3":
+    if workload in ("C3", "C3-bias"):
         lengths = torch.randint(0, 30, (B,), generator=gen, device=device, dtype=torch.int64)
         full = torch.rand(B, generator=gen, device=device) < 0.05
         return torch.where(full, torch.full_like(lengths, N), lengths)
@@ -110,7 +112,7 @@ def attention_section(args, rank, world, device):
         flops = layers * 4.0 * H * d * delta * float(L)            # every candidate row sees its user's whole history
         kernels["fwd"] = _launch.attn_fwd_kernel_name(dtype, d, d, N, heads=H)
         finite = lambda o: bool(torch.isfinite(o.float()).all())
-    elif wl == "C2":
+    elif wl in ("C2", "C3-bias"):
         from generative_recommenders_amd.research.modeling.sequential import hstu as R
 
         torch.manual_seed(5)
@@ -231,7 +233,7 @@ def rooflines(att, workload):
 
 
 # the other shapes north_star names, run for a few steps after the headline so that the driver's record carries them
-EXTRA_WORKLOADS = [("M-jag", {}), ("M-full-d64", {"workload": "M-full", "head_dim": 64}), ("C2", {}), ("C3", {})]
+EXTRA_WORKLOADS = [("M-jag", {}), ("M-full-d64", {"workload": "M-full", "head_dim": 64}), ("C2", {}), ("C3", {}), ("C3-bias", {})]
 
 
 def extra_workloads(args, rank, world, device):
@@ -429,7 +431,7 @@ def cpu_baseline(args):
     N, H, d = args.max_seq_len, args.heads, args.head_dim
     B = args.cpu_users
     gen = torch.Generator().manual_seed(1001)
-    lengths = make_lengths(args.workload if args.workload in ("M-full", "C2", "C3") else "M-jag", B, N, gen, "cpu")
+    lengths = make_lengths(args.workload if args.workload in ("M-full", "C2", "C3", "C3-bias") else "M-jag", B, N, gen, "cpu")
     off = torch.zeros(B + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(lengths, 0)
     L = int(off[-1])
@@ -614,7 +616,7 @@ def run(args):
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {args.users_per_gpu} users/GPU, L<= {N}, H={H}, dqk=dv={d}; {WORKLOADS[args.workload][4]}; "
-                        f"attention {what} via the C ABI" + ("" if args.workload in ("C2", "C5") else ", q/k/v strided views of one fused buffer"),
+                        f"attention {what} via the C ABI" + ("" if args.workload in ("C2", "C3-bias", "C5") else ", q/k/v strided views of one fused buffer"),
             "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "sort_by_length": args.sort_by_length, "parallelism": f"dp{world} (no collective: attention has no parameters)",
         },
         "device_ms_per_step": att["device_ms_per_step"], "step_spread": att["step_spread"],

@@ -42,6 +42,35 @@ bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {
   return aa == 0.f || (aa > 1e-20f && aa < 1e6f);
 }
 
+// LDS of the short-sequence research backward behind its four slices (`base`): histograms with as many time-bucket copies
+// as fit (32, 8 or 1), tables, the waves' private bucket bytes (`cache`)
+bool attn_solo_bias_lds(const HstuAttnParams& p, int base, int cache, int* ts_copies, int* hist_bytes, int* smem) {
+  const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
+  for (int c : {32, 8, 1}) {
+    const int hist = ((2 * p.max_seq_len + (p.num_buckets + 1) * c) * 4 + 15) / 16 * 16;
+    if (base + hist + tables + cache <= kLdsBudget) {
+      if (ts_copies) *ts_copies = c;
+      if (hist_bytes) *hist_bytes = hist;
+      if (smem) *smem = base + hist + tables + cache;
+      return true;
+    }
+  }
+  return false;
+}
+
+// research path at the short-sequence shapes (Amazon-Books: N = 61, 4 heads of 16): relative bias inside the one-wave-per-
+// (user, head) kernels.  16-bit I/O, max_seq_len <= 64, head dims <= 32, <= 255 time buckets (bucket bytes), no contextual
+// rows, no delta; HSTU_SOLO_BIAS=0: the general bias kernels (A/B measurements)
+bool attn_solo_bias_applicable(const HstuAttnParams& p, bool backward) {
+  static const bool enabled = [] { const char* e = getenv("HSTU_SOLO_BIAS"); return !(e && e[0] == '0'); }();
+  if (!enabled || !p.pos_w || p.dtype == HSTU_DTYPE_F32 || p.delta_q != 0 || p.contextual_seq_len > 0) return false;
+  if (p.max_seq_len > 64 || p.dqk > 32 || p.dv > 32 || p.num_buckets > 255) return false;
+  const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;          // masks ride on the S accumulator's start value (-1e30)
+  if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
+  if (!backward) return 4 * 6 * 2048 + bias_table_bytes(p.max_seq_len, p.num_buckets) + 3 * 1024 <= kLdsBudget;
+  return attn_solo_bias_lds(p, 4 * (8 * 2048 + 2 * 32 * 64), 3 * 1024, nullptr, nullptr, nullptr);
+}
+
 bool attn_bwd_quad_applicable(const HstuAttnBwdParams& bp) {
   static const bool enabled = [] { const char* e = getenv("HSTU_BWD_QUAD"); return !(e && e[0] == '0'); }();
   return enabled && attn_bwd_fold_applicable(bp) && bp.fwd.dqk == 64;
@@ -78,6 +107,7 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   if (a == 0 || v == 0) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "head dims (%d, %d) not instantiated", p.dqk, p.dv); }
   if (p.pos_w && a != v) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "relative-bias attention is instantiated for dqk == dv"); }
   if (attn_solo_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_kernel<%s>", bwd ? "bwd" : "fwd", dt);
+  else if (attn_solo_bias_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_bias_kernel<%s>", bwd ? "bwd" : "fwd", dt);
   else if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
   else if (bwd && attn_bwd_fold_bias_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_bias_kernel<%s,64>", dt);

@@ -28,4 +28,37 @@ static int launch_bwd_solo(const HstuAttnBwdParams& bp, hipStream_t st) {
   return check_launch("hstu_attn_bwd(solo)");
 }
 
+// research path (relative bias) at the short-sequence shapes: a workgroup per user at a time, its waves the heads
+template <typename T>
+static int launch_fwd_solo_bias(const HstuAttnParams& p, hipStream_t st) {
+  const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
+  const int smem = kSoloWaves * SoloCfg<T>::fwd_slice() + tables + kSoloBucketBytes;
+  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int per_cu = kLdsBudget / smem < 3 ? kLdsBudget / smem : 3;
+  const int grid = p.batch < per_cu * n_cu ? p.batch : per_cu * n_cu;
+  hipLaunchKernelGGL(hstu_attn_fwd_solo_bias_kernel<T>, dim3(grid), dim3(kSoloThreads), smem, st, p, tables);
+  return check_launch("hstu_attn_fwd(solo, bias)");
+}
+
+template <typename T>
+static int launch_bwd_solo_bias(const HstuAttnBwdParams& bp, hipStream_t st) {
+  const HstuAttnParams& p = bp.fwd;
+  int ts_copies = 1, hist = 0, smem = 0;
+  if (!attn_solo_bias_lds(p, kSoloWaves * SoloCfg<T>::bwd_slice(), kSoloBucketBytes, &ts_copies, &hist, &smem))
+    return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd(solo, bias): LDS");
+  const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
+  auto kern = hstu_attn_bwd_solo_bias_kernel<T>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int grid = p.batch < n_cu ? p.batch : n_cu;
+  const int hw = 2 * p.max_seq_len + p.num_buckets;
+  float* partial = (float*)bp.workspace;
+  e = hipMemsetAsync(partial, 0, (size_t)grid * hw * sizeof(float), st);
+  if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSoloThreads), smem, st, bp, partial, ts_copies, hist, tables);
+  if (int rc = check_launch("hstu_attn_bwd(solo, bias)")) return rc;
+  return launch_bias_grad_reduce(partial, grid, hw, 2 * p.max_seq_len - 1, bp.dpos_w, bp.dts_w, st);
+}
+
 }  // namespace hstu

@@ -31,6 +31,13 @@ int launch_attn_fwd_solo_f16(const HstuAttnParams& p, hipStream_t st);
 int launch_attn_bwd_solo_bf16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_solo_f16(const HstuAttnBwdParams& p, hipStream_t st);
 bool attn_solo_applicable(const HstuAttnParams& p, bool backward);
+// the same shapes with the research path's relative bias (hstu_attn_{fwd,bwd}_solo_bias_kernel; HSTU_SOLO_BIAS=0 disables)
+int launch_attn_fwd_solo_bias_bf16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_fwd_solo_bias_f16(const HstuAttnParams& p, hipStream_t st);
+int launch_attn_bwd_solo_bias_bf16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_solo_bias_f16(const HstuAttnBwdParams& p, hipStream_t st);
+bool attn_solo_bias_applicable(const HstuAttnParams& p, bool backward);
+bool attn_solo_bias_lds(const HstuAttnParams& p, int base, int cache, int* ts_copies, int* hist_bytes, int* smem);
 // ... and, among those, the ones the 4-wave / two-workgroups-per-CU kernel takes (head dim 64; HSTU_BWD_QUAD=0 disables)
 bool attn_bwd_quad_applicable(const HstuAttnBwdParams& p);
 // sums the per-workgroup bias-gradient rows: partial (rows, width) -> dpos_w (npos), dts_w (width - npos)

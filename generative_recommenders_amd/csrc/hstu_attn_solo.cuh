@@ -107,9 +107,58 @@ HSTU_DEV void solo_fwd_issue(const HstuAttnParams& p, const SoloProb& pr, u32x4 
   solo_issue<T>(rq, (const char*)p.q + (pr.off0 * p.q_row_stride + (int64_t)pr.hd * p.q_head_stride) * EB, p.q_row_stride * EB, pr.len, p.dqk, nt, lane);
 }
 
-// everything after the staging: the pairs of one problem from the wave's LDS slice, rows out
-template <typename T>
-HSTU_DEV void solo_fwd_compute(const HstuAttnParams& p, const SoloProb& pr, char* slice, int lane) {
+// Time buckets of one user as BYTES in LDS, computed once per user by the workgroup's four waves and read by every head:
+// 512 bytes per half tile (8 per lane), half tile (pair, h8) at ((pair * 2 + h8) * 512), pair = i (i + 1) / 2 + t for
+// query tile i, key tile t <= i.  Two layouts, each what its consumer's registers hold: forward S^T (lane = query,
+// registers = keys), backward S (lane = key, registers = queries: the layout of fold_pair_x's byte cache).
+constexpr int kSoloBucketBytes = 3 * 1024;
+template <bool BWD>
+HSTU_DEV void solo_bucket_bytes(const BiasCtx& bc, char* bcache, int len, int wave, int lane) {
+  const int n32 = lane & 31, hf = lane >> 5;
+  const int npairs = len > 32 ? 3 : 1;
+  for (int item = wave; item < 2 * npairs; item += kSoloWaves) {     // wave-uniform
+    const int pair = item >> 1, h8 = item & 1;
+    const int i = pair == 0 ? 0 : 1, t = pair == 2 ? 1 : 0;
+    int bkt[8];
+    if constexpr (BWD) {
+      const int key = 32 * t + n32;
+      if (bc.small) {
+        const int t_k32 = bc.t32_at(key);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const auto t4 = bc.t32x4_next(32 * i + 8 * (2 * h8 + g) + 4 * hf);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bkt[4 * g + j] = bc.bucket32(t4[j], t_k32);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * h8 + j;
+          bkt[j] = bc.bucket(bc.ts_at(32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf + 1), bc.ts_at(key));
+        }
+      }
+    } else {
+      const int qi = 32 * i + n32;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * h8 + j;
+        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        bkt[j] = bc.small ? bc.bucket32(bc.t32_at(qi + 1), bc.t32_at(key)) : bc.bucket(bc.ts_at(qi + 1), bc.ts_at(key));
+      }
+    }
+    u32x2 w = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j >> 2] |= (unsigned)bkt[j] << (8 * (j & 3));
+    *LDS_PTR(u32x2, bcache + item * 512 + 8 * lane) = w;
+  }
+}
+
+// everything after the staging: the pairs of one problem from the wave's LDS slice, rows out.  BIAS: the research path's
+// relative position / time-bucket term (hstu_attn_fwd.cuh, BIAS) from the workgroup's staged tables.
+struct SoloNoBias {};
+template <typename T, bool BIAS = false, typename BC = SoloNoBias>
+HSTU_DEV void solo_fwd_compute(const HstuAttnParams& p, const SoloProb& pr, char* slice, int lane, const BC& bc = BC(),
+                               const char* bcache = nullptr) {
   using S = SoloCfg<T>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -145,9 +194,17 @@ HSTU_DEV void solo_fwd_compute(const HstuAttnParams& p, const SoloProb& pr, char
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {
         float pv[8];
+        [[maybe_unused]] u32x2 bw = {0u, 0u};
+        if constexpr (BIAS) bw = *LDS_PTR(const u32x2, bcache + ((((i * (i + 1)) >> 1) + t) * 2 + h8) * 512 + 8 * lane);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float x = s[8 * h8 + j] * p.alpha;
+          float x = s[8 * h8 + j] * p.alpha;
+          if constexpr (BIAS) {
+            const int r = 8 * h8 + j;
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const int bkt = (int)((bw[j >> 2] >> (8 * (j & 3))) & 255u);
+            x += bc.value(bc.pos_index(32 * i + n32, key), bkt);
+          }
           pv[j] = x * fast_sigmoid(x);
         }
         pb[h8] = E::pack8(pv);
@@ -197,6 +254,56 @@ __global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_kernel(const 
   }
 }
 
+// Research path (relative position + time bias) at the short-sequence shapes (Amazon-Books: N = 61, 4 heads of 16): the
+// workgroup walks USERS -- tables and the user's timestamps staged once per user, two barriers -- and its four waves take
+// the user's heads (wave w: heads w, w + 4, ...); the user's time buckets are computed once, as bytes, by the four waves
+// together (a third barrier).  LDS: the four slices, the tables (bias_table_bytes), 3 KiB of bucket bytes.
+template <typename T>
+__global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_bias_kernel(const HstuAttnParams p, int table_bytes) {
+  using S = SoloCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* slice = smem + wave * S::fwd_slice();
+  char* const tables = smem + kSoloWaves * S::fwd_slice();
+  char* const bcache = tables + table_bytes;
+  bool first = true;                       // (the position / time tables are staged with the first user only)
+  for (int u = blockIdx.x; u < p.batch; u += gridDim.x) {
+    int u_l = u;
+    asm volatile("" : "+s"(u_l));
+    const int b = user_of_slot(p, u_l);
+    SoloProb cur;
+    cur.b = b;
+    cur.off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
+    cur.len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - cur.off0), kSoloMaxLen);
+    if (cur.len <= 0) continue;            // (workgroup-uniform)
+    // the wave's first head: its q, k, v rows are requested BEFORE the user's tables are staged -- the HBM round trip of
+    // the rows lies under the staging, its barriers and the bucket bytes instead of behind them
+    u32x4 rk[4], rv[4], rq[4];
+    cur.hd = wave;
+    if (wave < p.heads) solo_fwd_issue<T>(p, cur, rk, rv, rq, lane);
+    __syncthreads();                       // the previous user's pairs have read their last table entry and bucket byte
+    BiasCtx bc = stage_bias_tables(p, b, tables, tid, kSoloThreads, !first);
+    first = false;
+    __syncthreads();
+    bc.finish(kSoloWaves);
+    if (bc.lts) {                          // (position-only bias: bucket 0 everywhere, the bytes are not read)
+      solo_bucket_bytes<false>(bc, bcache, cur.len, wave, lane);
+      __syncthreads();
+    }
+    for (int hd = wave; hd < p.heads; hd += kSoloWaves) {
+      cur.hd = hd;
+      if (hd != wave) solo_fwd_issue<T>(p, cur, rk, rv, rq, lane);
+      const int nt = (cur.len + 31) >> 5;
+      solo_commit<T>(rk, slice, cur.len, p.dqk, nt, lane);
+      solo_commit<T>(rv, slice + 2 * S::TILE, cur.len, p.dv, nt, lane);
+      solo_commit<T>(rq, slice + 4 * S::TILE, cur.len, p.dqk, nt, lane);
+      solo_fwd_compute<T, true, BiasCtx>(p, cur, slice, lane, bc, bcache);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // dQ of query tile qt (rows 16 qb .. +16) from the wave's own dS' tiles: two interleaved 16x16x32 MFMAs per key tile
 // (quad_dq_phase with one feature block of 32)
@@ -229,13 +336,30 @@ HSTU_DEV void solo_dq(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char
   }
 }
 
+// the four row blocks of one (user, head) -> the wave's slice
 template <typename T>
-HSTU_DEV void solo_bwd_problem(const HstuAttnBwdParams& bp, int uh, char* slice, int lane) {
+HSTU_DEV void solo_bwd_stage(const HstuAttnBwdParams& bp, int b, int hd, char* slice, int lane) {
+  using S = SoloCfg<T>;
+  constexpr int EB = Elem<T>::kBytes;
+  const HstuAttnParams& p = bp.fwd;
+  const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
+  const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), kSoloMaxLen);
+  if (len <= 0) return;
+  const int nt = (len + 31) >> 5;
+  char* Kt = slice, *Vt = slice + 2 * S::TILE, *Qt = slice + 4 * S::TILE, *dOt = slice + 6 * S::TILE;
+  solo_stage<T>(Kt, (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * EB, p.k_row_stride * EB, len, p.dqk, nt, lane);
+  solo_stage<T>(Vt, (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * EB, p.v_row_stride * EB, len, p.dv, nt, lane);
+  solo_stage<T>(Qt, (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * EB, p.q_row_stride * EB, len, p.dqk, nt, lane);
+  solo_stage<T>(dOt, (const char*)bp.dout + (off0 * bp.do_row_stride + (int64_t)hd * bp.do_head_stride) * EB, bp.do_row_stride * EB, len, p.dv, nt, lane);
+}
+
+// `staged`: the caller has run solo_bwd_stage for this problem already
+template <typename T, typename BX = FoldNoBias>
+HSTU_DEV void solo_bwd_problem_x(const HstuAttnBwdParams& bp, int b, int hd, char* slice, int lane, BX& bx, bool staged = false) {
   using S = SoloCfg<T>;
   using C = BwdCfg<T, kSoloD, kSoloD>;
   constexpr int EB = Elem<T>::kBytes;
   const HstuAttnParams& p = bp.fwd;
-  const int b = user_of_slot(p, uh / p.heads), hd = uh % p.heads;
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
   const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), kSoloMaxLen);
   if (len <= 0) return;
@@ -243,10 +367,7 @@ HSTU_DEV void solo_bwd_problem(const HstuAttnBwdParams& bp, int uh, char* slice,
   HSTU_TRACE_DECL(bp.workspace, false);
   const int nt = (len + 31) >> 5;
   char* Kt = slice, *Vt = slice + 2 * S::TILE, *Qt = slice + 4 * S::TILE, *dOt = slice + 6 * S::TILE, *ds = slice + 8 * S::TILE;
-  solo_stage<T>(Kt, (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * EB, p.k_row_stride * EB, len, p.dqk, nt, lane);
-  solo_stage<T>(Vt, (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * EB, p.v_row_stride * EB, len, p.dv, nt, lane);
-  solo_stage<T>(Qt, (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * EB, p.q_row_stride * EB, len, p.dqk, nt, lane);
-  solo_stage<T>(dOt, (const char*)bp.dout + (off0 * bp.do_row_stride + (int64_t)hd * bp.do_head_stride) * EB, bp.do_row_stride * EB, len, p.dv, nt, lane);
+  if (!staged) solo_bwd_stage<T>(bp, b, hd, slice, lane);
   f32x16 dk0[1], dv0[1], dk1[1], dv1[1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk0[0][r] = 0.f; dv0[0][r] = 0.f; dk1[0][r] = 0.f; dv1[0][r] = 0.f; }
@@ -264,10 +385,10 @@ HSTU_DEV void solo_bwd_problem(const HstuAttnBwdParams& bp, int uh, char* slice,
   }
   for (int i = nt - 1; i >= 0; --i) {
     if (i >= 1 && (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 32, 32)))
-      fold_pair<T, kSoloD, kSoloD>(p, mc, Kt + S::TILE, Vt + S::TILE, Qt + i * S::TILE, dOt + i * S::TILE, ds + 32 * 64, 32 * i, 32, dk1, dv1, lane,
-                                   dmvm HSTU_TRACE_PASS);
+      fold_pair_x<T, kSoloD, kSoloD, BX>(p, mc, Kt + S::TILE, Vt + S::TILE, Qt + i * S::TILE, dOt + i * S::TILE, ds + 32 * 64, 32 * i, 32, dk1, dv1,
+                                         lane, dmvm, bx HSTU_TRACE_PASS);
     if (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 0, 32))
-      fold_pair<T, kSoloD, kSoloD>(p, mc, Kt, Vt, Qt + i * S::TILE, dOt + i * S::TILE, ds, 32 * i, 0, dk0, dv0, lane, dmvm HSTU_TRACE_PASS);
+      fold_pair_x<T, kSoloD, kSoloD, BX>(p, mc, Kt, Vt, Qt + i * S::TILE, dOt + i * S::TILE, ds, 32 * i, 0, dk0, dv0, lane, dmvm, bx HSTU_TRACE_PASS);
     solo_dq<T>(bp, mc, Kt, ds, i, 0, off0, hd, ds_scale, lane);
     solo_dq<T>(bp, mc, Kt, ds, i, 1, off0, hd, ds_scale, lane);
   }
@@ -285,6 +406,72 @@ HSTU_DEV void solo_bwd_problem(const HstuAttnBwdParams& bp, int uh, char* slice,
     solo_copy_out<T>(Vt + S::TILE, dv_head + 32 * bp.dv_row_stride * EB, bp.dv_row_stride * EB, len - 32, p.dv, lane);
   }
   (void)C::EB;
+}
+template <typename T>
+HSTU_DEV void solo_bwd_problem(const HstuAttnBwdParams& bp, int uh, char* slice, int lane) {
+  FoldNoBias nb;
+  solo_bwd_problem_x<T, FoldNoBias>(bp, user_of_slot(bp.fwd, uh / bp.fwd.heads), uh % bp.fwd.heads, slice, lane, nb);
+}
+
+// Research-path backward at the short-sequence shapes: as the forward above -- the workgroup walks users, its waves the
+// heads -- with the bias term and the two histograms of dS' of the folded research kernel (fold_pair_x<FoldBias>): ONE pair of
+// LDS histograms per workgroup for everything it processes, flushed to its row of `bias_partial` at the end; the user's
+// bucket bytes computed once by the four waves (fold_pair_x then always reads its byte cache).
+// LDS: [4 slices][pos histogram 2N | time histogram (nb+1) x ts_copies][tables][3 KiB bucket bytes].
+template <typename T>
+__global__ __launch_bounds__(kSoloThreads) void hstu_attn_bwd_solo_bias_kernel(const HstuAttnBwdParams bp, float* bias_partial, int ts_copies,
+                                                                              int hist_bytes, int table_bytes) {
+  using S = SoloCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const HstuAttnParams& p = bp.fwd;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* slice = smem + wave * S::bwd_slice();
+  FoldBias bx;
+  bx.hpos = (float*)(smem + kSoloWaves * S::bwd_slice());
+  bx.hts = bx.hpos + 2 * p.max_seq_len;
+  char* const tables = (char*)bx.hpos + hist_bytes;
+  bx.bcache = tables + table_bytes;
+  bx.ts_run.init(bx.hts, ts_copies);
+  bx.cached = true;
+  const int hist_floats = 2 * p.max_seq_len + (p.num_buckets + 1) * ts_copies;
+  for (int i = tid; i < hist_floats; i += kSoloThreads) bx.hpos[i] = 0.f;
+  bool first = true;
+  for (int u = blockIdx.x; u < p.batch; u += gridDim.x) {
+    int u_l = u;
+    asm volatile("" : "+s"(u_l));
+    const int b = user_of_slot(p, u_l);
+    // (the wave's first head: rows requested and written to the wave's own slice before the user's tables are staged)
+    if (wave < p.heads) solo_bwd_stage<T>(bp, b, wave, slice, lane);
+    __syncthreads();                       // histograms zeroed (first user) / the previous user's pairs are done with tables and bytes
+    bx.bc = stage_bias_tables(p, b, tables, tid, kSoloThreads, !first);
+    first = false;
+    __syncthreads();
+    bx.bc.finish(kSoloWaves);
+    {
+      const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - load_index(p.seq_offsets, b, p.offsets_dtype)), kSoloMaxLen);
+      solo_bucket_bytes<true>(bx.bc, bx.bcache, len, wave, lane);
+    }
+    __syncthreads();
+    for (int hd = wave; hd < p.heads; hd += kSoloWaves) solo_bwd_problem_x<T, FoldBias>(bp, b, hd, slice, lane, bx, hd == wave);
+  }
+  bx.ts_run.flush();
+  __syncthreads();
+  const float scale_v = attn_scale_of(p);
+  float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
+  const int npos = 2 * p.max_seq_len - 1;
+  for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kSoloThreads) {
+    float v;
+    if (i < npos) {
+      v = bx.hpos[i];
+    } else {
+      v = 0.f;
+      const float* cp = bx.hts + (i - npos) * ts_copies;
+      for (int c = 0; c < ts_copies; ++c) v += cp[c];
+    }
+    row[i] = v * scale_v;
+  }
 }
 
 template <typename T>

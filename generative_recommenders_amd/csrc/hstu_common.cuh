@@ -378,8 +378,10 @@ HSTU_DEV const int64_t* bias_ts_row(const HstuAttnParams& p, int b) {
   return (p.ts_w && p.timestamps) ? p.timestamps + (int64_t)b * p.ts_row_stride : nullptr;
 }
 
-// cooperative copy of the tables into `lds` (bias_table_bytes); the caller puts a barrier before the first use
-HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, int tid, int nthreads) {
+// cooperative copy of the tables into `lds` (bias_table_bytes); the caller puts a barrier before the first use.
+// `user_only`: the position / time tables are already there from an earlier call of this workgroup with the same `lds`
+// (they do not depend on the user): only the user's timestamps are staged.
+HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, int tid, int nthreads, bool user_only = false) {
   BiasCtx c;
   const int n = p.max_seq_len;
   // The position index n - 1 + key - query is formed for EVERY element of a tile, also for the query rows of the last
@@ -391,11 +393,14 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
   char* ltime = lts + ((p.num_buckets + 1) * 4 + 15) / 16 * 16;
   char* lt32 = ltime + (8 * n + 15) / 16 * 16;
   const int64_t* ts_row = bias_ts_row(p, b);
-  for (int i = tid; i < 32; i += nthreads) *LDS_PTR(float, lds + 4 * i) = 0.f;
-  for (int i = tid; i < 2 * n - 1; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = p.pos_w[i];
-  for (int i = 2 * n - 1 + tid; i < (int)(lts - lpos) / 4; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = 0.f;
+  if (!user_only) {
+    for (int i = tid; i < 32; i += nthreads) *LDS_PTR(float, lds + 4 * i) = 0.f;
+    for (int i = tid; i < 2 * n - 1; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = p.pos_w[i];
+    for (int i = 2 * n - 1 + tid; i < (int)(lts - lpos) / 4; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = 0.f;
+  }
   if (ts_row) {
-    for (int i = tid; i <= p.num_buckets; i += nthreads) *LDS_PTR(float, lts + 4 * i) = p.ts_w[i];
+    if (!user_only)
+      for (int i = tid; i <= p.num_buckets; i += nthreads) *LDS_PTR(float, lts + 4 * i) = p.ts_w[i];
     const int64_t t0 = ts_row[0];
     bool big = false;
     for (int i = tid; i < n; i += nthreads) {
@@ -411,7 +416,7 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
       *LDS_PTR(int, lt32 + 4 * (npad + i)) = i + 1 < n ? (int)(ts_row[i + 1] - t0) : last;
     const bool wave_big = __builtin_amdgcn_ballot_w64(big) != 0;
     if ((tid & 63) == 0) *LDS_PTR(int, lt32 + 4 * (2 * npad + (tid >> 6))) = wave_big ? 1 : 0;
-  } else {
+  } else if (!user_only) {
     // position-only bias with n < 32: indices up to n + 30 run past the position table into this slot
     for (int i = tid; i < (int)(ltime - lts) / 4; i += nthreads) *LDS_PTR(float, lts + 4 * i) = 0.f;
   }

@@ -74,6 +74,9 @@ def test_no_kernel_spills_or_uses_scratch():
     # u * GroupNorm(attn) backward with SiLU applied on the fly (single-chunk rows): 98 registers, asked to fit the 96 of a
     # fifth wave per SIMD -- 2 spilled registers, measured 4 % faster than 4 waves without (profiles/r03_ab_row_passes_silu.txt)
     bounded.update({"norm_mul_bwd_gn_kernelIDF16bLi8ELi1ELb1E": 2, "norm_mul_bwd_gn_kernelIDF16_Li8ELi1ELb1E": 2})
+    # The short-sequence research backward (one workgroup per CU, one wave per SIMD: 344 registers incl. AGPRs) parks one
+    # 8-byte value in scratch at entry (no register spilled in the loops' bodies)
+    bounded.update({"hstu_attn_bwd_solo_bias_kernel": 0})
     bad = {k: v for k, v in ks.items() if (v["spill"] or v["scratch"]) and "hstu" in k and not any(a in k for a in accepted)
            and not any(b in k and v["spill"] <= n for b, n in bounded.items())}
     assert not bad, f"kernels with register spills / scratch: {bad}"

@@ -155,6 +155,56 @@ def test_folded_bias_backward_many_users_per_workgroup(dtype, H, n, B):
     _close(ts_w.grad, rts, 2e-3, 1e-4, f"dts_w[{tag} folded]")
 
 
+@pytest.mark.parametrize("dtype,H,d,n,B,with_ts", [(torch.bfloat16, 4, 16, 61, 700, True), (torch.float16, 6, 32, 64, 300, True),
+                                                    (torch.bfloat16, 1, 8, 17, 500, True), (torch.bfloat16, 3, 24, 33, 400, False),
+                                                    (torch.bfloat16, 2, 16, 61, 3, True)])
+def test_short_sequence_bias_kernels(dtype, H, d, n, B, with_ts):
+    """The research path at the Amazon-Books shapes (N <= 64, head dims <= 32, 16-bit): hstu_attn_{fwd,bwd}_solo_bias_kernel --
+    a workgroup per user at a time, its four waves the heads (more heads than waves, one head, fewer users than CUs), tables
+    restaged per user, ONE histogram pair per persistent workgroup.  Long-tail lengths with empty users and full-length ones;
+    position + time tables and position-only.  Against the fp64 oracle."""
+    from generative_recommenders_amd.ops import _launch
+    from test_configs_gpu import _timestamps_off_bucket_boundaries
+
+    m = _mods()
+    assert _launch.attn_bwd_kernel_name(dtype, d, d, n, heads=H, with_bias=True).startswith("hstu_attn_bwd_solo_bias_kernel")
+    assert _launch.attn_fwd_kernel_name(dtype, d, d, n, heads=H, with_bias=True).startswith("hstu_attn_fwd_solo_bias_kernel")
+    torch.manual_seed(n + B)
+    rng = np.random.default_rng(n + B)
+    lengths = rng.integers(0, max(n // 2, 2), size=B)
+    lengths[rng.random(B) < 0.05] = n
+    lengths[:3] = [n, 0, 1]
+    off = O.complete_cumsum(lengths.astype(np.int64))
+    Lt = int(off[-1])
+    ts = _timestamps_off_bucket_boundaries(rng, B, n)
+    mk = lambda: torch.from_numpy(rng.standard_normal((Lt, H * d)) * 0.5).to(dtype)
+    q, k, v = mk(), mk(), mk()
+    g = torch.from_numpy(rng.standard_normal((Lt, H * d))).to(dtype)
+    bias = (m.RelativeBucketedTimeAndPositionBasedBias(n, 128) if with_ts else m.RelativePositionalBias(n)).to(DEV)
+    with torch.no_grad():
+        for prm in bias.parameters():
+            prm.normal_(0, 0.05)
+    pos_w, ts_w, _, _ = bias.bias_params()
+    qd, kd, vd = (t.to(DEV).requires_grad_() for t in (q, k, v))
+    out = m.hstu_rel_bias_attention(H, d, d, qd, kd, vd, torch.from_numpy(off).to(DEV), torch.from_numpy(ts).to(DEV), n, bias)
+    out.backward(g.to(DEV))
+    pw = pos_w.detach().double().cpu().numpy()
+    tw = None if ts_w is None else ts_w.detach().double().cpu().numpy()
+    q3, k3, v3 = (t.double().numpy().reshape(Lt, H, d) for t in (q, k, v))
+    ref = O.rel_bias_attention_fwd(n, q3, k3, v3, off, ts if with_ts else None, pw, tw)
+    rq, rk, rv, rpos, rts = O.rel_bias_attention_bwd(n, g.double().numpy().reshape(Lt, H, d), q3, k3, v3, off,
+                                                     ts if with_ts else None, pw, tw)
+    tol = (3e-2, 6e-3)
+    tag = str(dtype).replace("torch.", "")
+    _close(out, ref.reshape(Lt, -1), *tol, "out")
+    _close(qd.grad, rq.reshape(Lt, -1), *tol, "dq")
+    _close(kd.grad, rk.reshape(Lt, -1), *tol, "dk")
+    _close(vd.grad, rv.reshape(Lt, -1), *tol, "dv")
+    _close(pos_w.grad, rpos, 2e-3, 1e-4, f"dpos_w[{tag} solo]")
+    if with_ts:
+        _close(ts_w.grad, rts, 2e-3, 1e-4, f"dts_w[{tag} solo]")
+
+
 def test_research_layer_forward_backward_runs_and_matches_composition():
     """SequentialTransductionUnitJagged on the fused kernels == the same math composed from the
     oracle pieces (LN without affine -> uvqk -> SiLU on all -> bias attention -> u * LN(attn) -> Linear + x)."""

@@ -8,8 +8,14 @@ import generative_recommenders_amd.research.modeling.sequential.hstu as R
 from generative_recommenders_amd.ops.hstu_attention import hstu_mha
 dev = "cuda"
 torch.manual_seed(0)
-B, n, H, d = 8192, 211, 4, 64
-lengths = torch.randint(n // 2, n + 1, (B,), device=dev)
+# `books`: the Amazon-Books research configuration (N = 61, 4 heads of 16, long-tail lengths: randint(0, 30), 5 % at 61)
+if len(sys.argv) > 1 and sys.argv[1] == "books":
+    B, n, H, d = 8192, 61, 4, 16
+    lengths = torch.randint(1, 30, (B,), device=dev)
+    lengths[torch.rand(B, device=dev) < 0.05] = n
+else:
+    B, n, H, d = 8192, 211, 4, 64
+    lengths = torch.randint(n // 2, n + 1, (B,), device=dev)
 off = torch.zeros(B + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(lengths, 0)
 L = int(off[-1])
 ts = torch.sort(torch.randint(0, 10**8, (B, n), device=dev), dim=1).values
@@ -66,3 +72,13 @@ r["with_bias_bwd_GBps"] = bwd_b / (r["with_bias_fwd_bwd_ms"] - r["with_bias_fwd_
 r["plain_fwd_GBps"] = fwd_b / r["plain_fwd_ms"] / 1e6
 r["plain_bwd_GBps"] = bwd_b / (r["plain_fwd_bwd_ms"] - r["plain_fwd_ms"]) / 1e6
 print(json.dumps({k_: round(v_, 3) if isinstance(v_, float) else v_ for k_, v_ in r.items()}, indent=1))
+
+if "--kernels" in sys.argv:       # device time per kernel of the with-bias forward + backward (is the op call launch-bound?)
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(10):
+            fb_bias()
+        torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)
+    for e in rows[:12]:
+        print(f"{e.self_device_time_total / 10:9.1f} us/iter  n={e.count // 10:3d}  {e.key[:110]}")
