@@ -45,7 +45,7 @@ bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {
 // LDS of the short-sequence research backward behind its four slices (`base`): histograms with as many time-bucket copies
 // as fit (32, 8 or 1), tables, the waves' private bucket bytes (`cache`)
 bool attn_solo_bias_lds(const HstuAttnParams& p, int base, int cache, int* ts_copies, int* hist_bytes, int* smem) {
-  const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
+  const int tables = 2 * bias_table_bytes(p.max_seq_len, p.num_buckets);      // (double-buffered: hstu_attn_solo.cuh)
   for (int c : {32, 8, 1}) {
     const int hist = ((2 * p.max_seq_len + (p.num_buckets + 1) * c) * 4 + 15) / 16 * 16;
     if (base + hist + tables + cache <= kLdsBudget) {
@@ -67,8 +67,9 @@ bool attn_solo_bias_applicable(const HstuAttnParams& p, bool backward) {
   if (p.max_seq_len > 64 || p.dqk > 32 || p.dv > 32 || p.num_buckets > 255) return false;
   const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;          // masks ride on the S accumulator's start value (-1e30)
   if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
-  if (!backward) return 4 * 6 * 2048 + bias_table_bytes(p.max_seq_len, p.num_buckets) + 3 * 1024 <= kLdsBudget;
-  return attn_solo_bias_lds(p, 4 * (8 * 2048 + 2 * 32 * 64), 3 * 1024, nullptr, nullptr, nullptr);
+  if (p.max_seq_len + 32 + 3 > 256) return false;      // (a thread per timestamp entry)
+  if (!backward) return 4 * (6 * 2048 + bias_table_bytes(p.max_seq_len, p.num_buckets) + 3 * 1024) <= kLdsBudget;
+  return attn_solo_bias_lds(p, 4 * (8 * 2048 + 2 * 32 * 64), 2 * 3 * 1024, nullptr, nullptr, nullptr);
 }
 
 bool attn_bwd_quad_applicable(const HstuAttnBwdParams& bp) {

@@ -1,6 +1,8 @@
 // Launchers of the short-sequence kernels (hstu_attn_solo.cuh): one wave per (user, head).
 #pragma once
 #include "capi_internal.h"
+#include <stdlib.h>
+
 #include "hstu_attn_solo.cuh"
 
 namespace hstu {
@@ -28,23 +30,30 @@ static int launch_bwd_solo(const HstuAttnBwdParams& bp, hipStream_t st) {
   return check_launch("hstu_attn_bwd(solo)");
 }
 
-// research path (relative bias) at the short-sequence shapes: a workgroup per user at a time, its waves the heads
+// research path (relative bias) at the short-sequence shapes.  Forward: a wave per user (its own tables and bucket bytes)
 template <typename T>
 static int launch_fwd_solo_bias(const HstuAttnParams& p, hipStream_t st) {
   const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
-  const int smem = kSoloWaves * SoloCfg<T>::fwd_slice() + tables + kSoloBucketBytes;
+  const int smem = kSoloWaves * (SoloCfg<T>::fwd_slice() + tables + kSoloBucketBytes);
   static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  auto kern = hstu_attn_fwd_solo_bias_kernel<T>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_fwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+  }
   const int per_cu = kLdsBudget / smem < 3 ? kLdsBudget / smem : 3;
-  const int grid = p.batch < per_cu * n_cu ? p.batch : per_cu * n_cu;
-  hipLaunchKernelGGL(hstu_attn_fwd_solo_bias_kernel<T>, dim3(grid), dim3(kSoloThreads), smem, st, p, tables);
+  const int wgs = (p.batch + kSoloWaves - 1) / kSoloWaves;
+  const int grid = wgs < per_cu * n_cu ? wgs : per_cu * n_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kSoloThreads), smem, st, p, tables);
   return check_launch("hstu_attn_fwd(solo, bias)");
 }
 
+// backward: a workgroup per user at a time, its waves the heads
 template <typename T>
 static int launch_bwd_solo_bias(const HstuAttnBwdParams& bp, hipStream_t st) {
   const HstuAttnParams& p = bp.fwd;
   int ts_copies = 1, hist = 0, smem = 0;
-  if (!attn_solo_bias_lds(p, kSoloWaves * SoloCfg<T>::bwd_slice(), kSoloBucketBytes, &ts_copies, &hist, &smem))
+  if (!attn_solo_bias_lds(p, kSoloWaves * SoloCfg<T>::bwd_slice(), 2 * kSoloBucketBytes, &ts_copies, &hist, &smem))
     return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd(solo, bias): LDS");
   const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
   auto kern = hstu_attn_bwd_solo_bias_kernel<T>;

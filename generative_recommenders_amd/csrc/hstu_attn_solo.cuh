@@ -113,10 +113,10 @@ HSTU_DEV void solo_fwd_issue(const HstuAttnParams& p, const SoloProb& pr, u32x4 
 // registers = keys), backward S (lane = key, registers = queries: the layout of fold_pair_x's byte cache).
 constexpr int kSoloBucketBytes = 3 * 1024;
 template <bool BWD>
-HSTU_DEV void solo_bucket_bytes(const BiasCtx& bc, char* bcache, int len, int wave, int lane) {
+HSTU_DEV void solo_bucket_bytes(const BiasCtx& bc, char* bcache, int len, int wave, int lane, int nwaves = kSoloWaves) {
   const int n32 = lane & 31, hf = lane >> 5;
   const int npairs = len > 32 ? 3 : 1;
-  for (int item = wave; item < 2 * npairs; item += kSoloWaves) {     // wave-uniform
+  for (int item = wave; item < 2 * npairs; item += nwaves) {     // wave-uniform
     const int pair = item >> 1, h8 = item & 1;
     const int i = pair == 0 ? 0 : 1, t = pair == 2 ? 1 : 0;
     int bkt[8];
@@ -254,51 +254,88 @@ __global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_kernel(const 
   }
 }
 
-// Research path (relative position + time bias) at the short-sequence shapes (Amazon-Books: N = 61, 4 heads of 16): the
-// workgroup walks USERS -- tables and the user's timestamps staged once per user, two barriers -- and its four waves take
-// the user's heads (wave w: heads w, w + 4, ...); the user's time buckets are computed once, as bytes, by the four waves
-// together (a third barrier).  LDS: the four slices, the tables (bias_table_bytes), 3 KiB of bucket bytes.
+// Research path (relative position + time bias) at the short-sequence shapes (Amazon-Books: N = 61, 4 heads of 16).
+// Helpers of the BACKWARD kernel's software pipeline over the users (further down): the user part of stage_bias_tables
+// split into its loads (registers) and its LDS writes.
+struct SoloTs { int64_t t, tn, t0, tl; };     // thread i: t[i], t[i + 1], t[0], t[n - 1] of the user's timestamp row (clamped)
+HSTU_DEV void solo_ts_issue(const HstuAttnParams& p, int b, int tid, SoloTs& r) {
+  const int64_t* ts_row = bias_ts_row(p, b);
+  if (!ts_row) return;                          // (kernel-uniform)
+  const int n = p.max_seq_len;
+  r.t = ts_row[min(tid, n - 1)];
+  r.tn = ts_row[min(tid + 1, n - 1)];
+  r.t0 = ts_row[0];
+  r.tl = ts_row[n - 1];
+}
+// the user part of stage_bias_tables from registers (max_seq_len + 32 <= the workgroup's threads: thread i writes entry i)
+HSTU_DEV BiasCtx solo_ts_commit(const HstuAttnParams& p, char* lds, int tid, const SoloTs& r) {
+  const bool has_ts = p.ts_w && p.timestamps;
+  const BiasCtx c = bias_ctx_at(p, has_ts, lds);
+  if (has_ts) {
+    const int n = p.max_seq_len;
+    bool big = false;
+    if (tid < c.npad) {
+      const int64_t o = r.t - r.t0;
+      if (tid < n) {
+        *LDS_PTR(int64_t, c.ltime + 8 * tid) = r.t;
+        big = o >= (1LL << 30) || o <= -(1LL << 30);
+      }
+      *LDS_PTR(int, c.lt32 + 4 * tid) = (int)o;                                   // (entries >= n: the last timestamp, clamped above)
+      *LDS_PTR(int, c.lt32 + 4 * (c.npad + tid)) = (int)(r.tn - r.t0);           // shifted copy: entry i = t[i + 1]
+    }
+    const bool wave_big = __builtin_amdgcn_ballot_w64(big) != 0;
+    if ((tid & 63) == 0) *LDS_PTR(int, c.lt32 + 4 * (2 * c.npad + (tid >> 6))) = wave_big ? 1 : 0;
+  }
+  return c;
+}
+HSTU_DEV SoloProb solo_user(const HstuAttnParams& p, int u, int hd) {      // u clamped: every load is a valid one
+  SoloProb r;
+  r.b = user_of_slot(p, min(u, p.batch - 1));
+  r.hd = hd;
+  r.off0 = load_index(p.seq_offsets, r.b, p.offsets_dtype);
+  r.len = min((int)(load_index(p.seq_offsets, r.b + 1, p.offsets_dtype) - r.off0), kSoloMaxLen);
+  return r;
+}
+
+// Forward: NOTHING is shared between the waves.  A wave owns a USER -- its own copy of the tables, its own bucket bytes
+// (computed once, read by every head), its slice -- and walks the user's heads, the next head's rows requested under the
+// current head's pairs; no barrier anywhere, the waves of a CU drift apart and fill each other's waits (as in the plain
+// short-sequence kernel).  LDS per wave: slice + tables + 3 KiB of bucket bytes.  (A workgroup per user with its waves on
+// the heads, software-pipelined over the users as the backward below, was measured too: 143 vs 135 us on the Amazon-Books
+// batch.  By removal, of those 135-144 us the pairs are 71, the bucket bytes 37, the row loads 18, the rest 24.)
 template <typename T>
 __global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_bias_kernel(const HstuAttnParams p, int table_bytes) {
   using S = SoloCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* slice = smem + wave * S::fwd_slice();
-  char* const tables = smem + kSoloWaves * S::fwd_slice();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int per_wave = S::fwd_slice() + table_bytes + kSoloBucketBytes;
+  char* slice = smem + wave * per_wave;
+  char* const tables = slice + S::fwd_slice();
   char* const bcache = tables + table_bytes;
-  bool first = true;                       // (the position / time tables are staged with the first user only)
-  for (int u = blockIdx.x; u < p.batch; u += gridDim.x) {
+  bool first = true;
+  for (int u = blockIdx.x * kSoloWaves + wave; u < p.batch; u += gridDim.x * kSoloWaves) {
     int u_l = u;
     asm volatile("" : "+s"(u_l));
-    const int b = user_of_slot(p, u_l);
-    SoloProb cur;
-    cur.b = b;
-    cur.off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
-    cur.len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - cur.off0), kSoloMaxLen);
-    if (cur.len <= 0) continue;            // (workgroup-uniform)
-    // the wave's first head: its q, k, v rows are requested BEFORE the user's tables are staged -- the HBM round trip of
-    // the rows lies under the staging, its barriers and the bucket bytes instead of behind them
+    SoloProb cur = solo_user(p, u_l, 0);
+    if (cur.len <= 0) continue;
     u32x4 rk[4], rv[4], rq[4];
-    cur.hd = wave;
-    if (wave < p.heads) solo_fwd_issue<T>(p, cur, rk, rv, rq, lane);
-    __syncthreads();                       // the previous user's pairs have read their last table entry and bucket byte
-    BiasCtx bc = stage_bias_tables(p, b, tables, tid, kSoloThreads, !first);
+    solo_fwd_issue<T>(p, cur, rk, rv, rq, lane);                    // head 0: under the staging of the user's tables
+    BiasCtx bc = stage_bias_tables(p, cur.b, tables, lane, 64, !first);
     first = false;
-    __syncthreads();
-    bc.finish(kSoloWaves);
-    if (bc.lts) {                          // (position-only bias: bucket 0 everywhere, the bytes are not read)
-      solo_bucket_bytes<false>(bc, bcache, cur.len, wave, lane);
-      __syncthreads();
-    }
-    for (int hd = wave; hd < p.heads; hd += kSoloWaves) {
+    bc.finish(1);                                                    // (LDS operations of a wave complete in order: no barrier)
+    if (bc.lts) solo_bucket_bytes<false>(bc, bcache, cur.len, 0, lane, 1);
+    const int nt = (cur.len + 31) >> 5;
+    for (int hd = 0; hd < p.heads; ++hd) {
       cur.hd = hd;
-      if (hd != wave) solo_fwd_issue<T>(p, cur, rk, rv, rq, lane);
-      const int nt = (cur.len + 31) >> 5;
       solo_commit<T>(rk, slice, cur.len, p.dqk, nt, lane);
       solo_commit<T>(rv, slice + 2 * S::TILE, cur.len, p.dv, nt, lane);
       solo_commit<T>(rq, slice + 4 * S::TILE, cur.len, p.dqk, nt, lane);
+      if (hd + 1 < p.heads) {                                        // the next head's rows: in flight during this head's pairs
+        SoloProb nx = cur;
+        nx.hd = hd + 1;
+        solo_fwd_issue<T>(p, nx, rk, rv, rq, lane);
+      }
       solo_fwd_compute<T, true, BiasCtx>(p, cur, slice, lane, bc, bcache);
     }
   }
@@ -336,7 +373,28 @@ HSTU_DEV void solo_dq(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char
   }
 }
 
-// the four row blocks of one (user, head) -> the wave's slice
+// the four row blocks of one (user, head): requested (registers) / written to the wave's slice
+template <typename T>
+HSTU_DEV void solo_bwd_issue(const HstuAttnBwdParams& bp, const SoloProb& pr, u32x4 (&rk)[4], u32x4 (&rv)[4], u32x4 (&rq)[4], u32x4 (&rd)[4], int lane) {
+  constexpr int EB = Elem<T>::kBytes;
+  const HstuAttnParams& p = bp.fwd;
+  const int nt = (pr.len + 31) >> 5;
+  solo_issue<T>(rk, (const char*)p.k + (pr.off0 * p.k_row_stride + (int64_t)pr.hd * p.k_head_stride) * EB, p.k_row_stride * EB, pr.len, p.dqk, nt, lane);
+  solo_issue<T>(rv, (const char*)p.v + (pr.off0 * p.v_row_stride + (int64_t)pr.hd * p.v_head_stride) * EB, p.v_row_stride * EB, pr.len, p.dv, nt, lane);
+  solo_issue<T>(rq, (const char*)p.q + (pr.off0 * p.q_row_stride + (int64_t)pr.hd * p.q_head_stride) * EB, p.q_row_stride * EB, pr.len, p.dqk, nt, lane);
+  solo_issue<T>(rd, (const char*)bp.dout + (pr.off0 * bp.do_row_stride + (int64_t)pr.hd * bp.do_head_stride) * EB, bp.do_row_stride * EB, pr.len, p.dv, nt, lane);
+}
+template <typename T>
+HSTU_DEV void solo_bwd_commit(const HstuAttnBwdParams& bp, const SoloProb& pr, const u32x4 (&rk)[4], const u32x4 (&rv)[4], const u32x4 (&rq)[4],
+                              const u32x4 (&rd)[4], char* slice, int lane) {
+  using S = SoloCfg<T>;
+  const HstuAttnParams& p = bp.fwd;
+  const int nt = (pr.len + 31) >> 5;
+  solo_commit<T>(rk, slice, pr.len, p.dqk, nt, lane);
+  solo_commit<T>(rv, slice + 2 * S::TILE, pr.len, p.dv, nt, lane);
+  solo_commit<T>(rq, slice + 4 * S::TILE, pr.len, p.dqk, nt, lane);
+  solo_commit<T>(rd, slice + 6 * S::TILE, pr.len, p.dv, nt, lane);
+}
 template <typename T>
 HSTU_DEV void solo_bwd_stage(const HstuAttnBwdParams& bp, int b, int hd, char* slice, int lane) {
   using S = SoloCfg<T>;
@@ -417,7 +475,7 @@ HSTU_DEV void solo_bwd_problem(const HstuAttnBwdParams& bp, int uh, char* slice,
 // heads -- with the bias term and the two histograms of dS' of the folded research kernel (fold_pair_x<FoldBias>): ONE pair of
 // LDS histograms per workgroup for everything it processes, flushed to its row of `bias_partial` at the end; the user's
 // bucket bytes computed once by the four waves (fold_pair_x then always reads its byte cache).
-// LDS: [4 slices][pos histogram 2N | time histogram (nb+1) x ts_copies][tables][3 KiB bucket bytes].
+// LDS: [4 slices][pos histogram 2N | time histogram (nb+1) x ts_copies][2 x (tables | 3 KiB bucket bytes)].
 template <typename T>
 __global__ __launch_bounds__(kSoloThreads) void hstu_attn_bwd_solo_bias_kernel(const HstuAttnBwdParams bp, float* bias_partial, int ts_copies,
                                                                               int hist_bytes, int table_bytes) {
@@ -431,30 +489,45 @@ __global__ __launch_bounds__(kSoloThreads) void hstu_attn_bwd_solo_bias_kernel(c
   FoldBias bx;
   bx.hpos = (float*)(smem + kSoloWaves * S::bwd_slice());
   bx.hts = bx.hpos + 2 * p.max_seq_len;
-  char* const tables = (char*)bx.hpos + hist_bytes;
-  bx.bcache = tables + table_bytes;
+  char* const tab0 = (char*)bx.hpos + hist_bytes;
+  const int tab_stride = table_bytes + kSoloBucketBytes;
   bx.ts_run.init(bx.hts, ts_copies);
   bx.cached = true;
   const int hist_floats = 2 * p.max_seq_len + (p.num_buckets + 1) * ts_copies;
   for (int i = tid; i < hist_floats; i += kSoloThreads) bx.hpos[i] = 0.f;
-  bool first = true;
-  for (int u = blockIdx.x; u < p.batch; u += gridDim.x) {
-    int u_l = u;
-    asm volatile("" : "+s"(u_l));
-    const int b = user_of_slot(p, u_l);
-    // (the wave's first head: rows requested and written to the wave's own slice before the user's tables are staged)
-    if (wave < p.heads) solo_bwd_stage<T>(bp, b, wave, slice, lane);
-    __syncthreads();                       // histograms zeroed (first user) / the previous user's pairs are done with tables and bytes
-    bx.bc = stage_bias_tables(p, b, tables, tid, kSoloThreads, !first);
-    first = false;
+  const int hd0 = min(wave, p.heads - 1);
+  const int grid = gridDim.x;
+  {
+    const int b0 = user_of_slot(p, blockIdx.x);
+    stage_bias_tables(p, b0, tab0, tid, kSoloThreads);
+    stage_bias_tables(p, b0, tab0 + tab_stride, tid, kSoloThreads);
+  }
+  // the same software pipeline over the users as the forward kernel: rows / timestamps of the next user, offsets of the
+  // one after, requested while this one is worked on; tables and bucket bytes double-buffered
+  SoloProb cur = solo_user(p, blockIdx.x, hd0), nxt = solo_user(p, blockIdx.x + grid, hd0);
+  u32x4 rk[4], rv[4], rq[4], rd[4];
+  SoloTs ts = {0, 0, 0, 0};
+  solo_bwd_issue<T>(bp, cur, rk, rv, rq, rd, lane);
+  solo_ts_issue(p, cur.b, tid, ts);
+  __syncthreads();                         // histograms zeroed, tables in place
+  int buf = 0;
+  for (int u = blockIdx.x; u < p.batch; u += grid) {
+    char* const tables = tab0 + buf * tab_stride;
+    bx.bcache = tables + table_bytes;
+    solo_bwd_commit<T>(bp, cur, rk, rv, rq, rd, slice, lane);
+    bx.bc = solo_ts_commit(p, tables, tid, ts);
+    const SoloProb pf = (u + grid < p.batch) ? nxt : cur;
+    solo_bwd_issue<T>(bp, pf, rk, rv, rq, rd, lane);
+    solo_ts_issue(p, pf.b, tid, ts);
+    const SoloProb nn = solo_user(p, u + 2 * grid, hd0);
     __syncthreads();
     bx.bc.finish(kSoloWaves);
-    {
-      const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - load_index(p.seq_offsets, b, p.offsets_dtype)), kSoloMaxLen);
-      solo_bucket_bytes<true>(bx.bc, bx.bcache, len, wave, lane);
-    }
+    solo_bucket_bytes<true>(bx.bc, bx.bcache, cur.len, wave, lane);
     __syncthreads();
-    for (int hd = wave; hd < p.heads; hd += kSoloWaves) solo_bwd_problem_x<T, FoldBias>(bp, b, hd, slice, lane, bx, hd == wave);
+    for (int hd = wave; hd < p.heads; hd += kSoloWaves) solo_bwd_problem_x<T, FoldBias>(bp, cur.b, hd, slice, lane, bx, hd == wave);
+    cur = nxt;
+    nxt = nn;
+    buf ^= 1;
   }
   bx.ts_run.flush();
   __syncthreads();

@@ -381,18 +381,39 @@ HSTU_DEV const int64_t* bias_ts_row(const HstuAttnParams& p, int b) {
 // cooperative copy of the tables into `lds` (bias_table_bytes); the caller puts a barrier before the first use.
 // `user_only`: the position / time tables are already there from an earlier call of this workgroup with the same `lds`
 // (they do not depend on the user): only the user's timestamps are staged.
-HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, int tid, int nthreads, bool user_only = false) {
+// the context of tables laid out at `lds` (the layout stage_bias_tables fills)
+HSTU_DEV BiasCtx bias_ctx_at(const HstuAttnParams& p, bool has_ts, char* lds) {
   BiasCtx c;
+  const int n = p.max_seq_len;
+  char* lpos = lds + 128;
+  char* lts = lpos + (2 * n * 4 + 15) / 16 * 16;
+  char* ltime = lts + ((p.num_buckets + 1) * 4 + 15) / 16 * 16;
+  char* lt32 = ltime + (8 * n + 15) / 16 * 16;
+  c.lt32 = lt32;
+  c.npad = (n + 32 + 3) / 4 * 4;
+  c.small = false;
+  c.lpos = lpos;
+  c.lts = has_ts ? lts : nullptr;
+  c.ltime = has_ts ? ltime : nullptr;
+  c.n = n;
+  c.nb = p.num_buckets;
+  c.div = p.bucket_div;
+  c.kf = 0.69314718055994530942f / p.bucket_div;
+  return c;
+}
+
+HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, int tid, int nthreads, bool user_only = false) {
   const int n = p.max_seq_len;
   // The position index n - 1 + key - query is formed for EVERY element of a tile, also for the query rows of the last
   // tile that lie past max_seq_len (masked, but their value still passes through silu and a 0 x value product): down to
   // -31.  Those reads must see finite numbers whatever the previous kernel left in LDS (a NaN there survives 0 x NaN):
   // 32 zeros in front of the table, zeros behind its 2n - 1 entries.
+  const int64_t* ts_row = bias_ts_row(p, b);
+  const BiasCtx c = bias_ctx_at(p, ts_row != nullptr, lds);
   char* lpos = lds + 128;
   char* lts = lpos + (2 * n * 4 + 15) / 16 * 16;
   char* ltime = lts + ((p.num_buckets + 1) * 4 + 15) / 16 * 16;
   char* lt32 = ltime + (8 * n + 15) / 16 * 16;
-  const int64_t* ts_row = bias_ts_row(p, b);
   if (!user_only) {
     for (int i = tid; i < 32; i += nthreads) *LDS_PTR(float, lds + 4 * i) = 0.f;
     for (int i = tid; i < 2 * n - 1; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = p.pos_w[i];
@@ -420,16 +441,6 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
     // position-only bias with n < 32: indices up to n + 30 run past the position table into this slot
     for (int i = tid; i < (int)(ltime - lts) / 4; i += nthreads) *LDS_PTR(float, lts + 4 * i) = 0.f;
   }
-  c.lt32 = lt32;
-  c.npad = (n + 32 + 3) / 4 * 4;
-  c.small = false;
-  c.lpos = lpos;
-  c.lts = ts_row ? lts : nullptr;
-  c.ltime = ts_row ? ltime : nullptr;
-  c.n = n;
-  c.nb = p.num_buckets;
-  c.div = p.bucket_div;
-  c.kf = 0.69314718055994530942f / p.bucket_div;
   return c;
 }
 
