@@ -90,9 +90,15 @@ bool attn_fwd_head_loop_applicable(const HstuAttnParams& p, int ring_bytes, int*
   const int q_rows = p.delta_q > 0 ? p.delta_q : p.max_seq_len;
   const int nqb = (q_rows + 127) / 128, tmax = (p.max_seq_len + 31) / 32;
   const int tables = p.pos_w ? bias_table_bytes(p.max_seq_len, p.num_buckets) : 0;
-  int cache = 0;      // the last query block keeps the most: 1 KiB per key tile and wave
-  for (int w = 0; w < 4; ++w)
-    if (4 * (nqb - 1) + w < tmax) cache += (4 * (nqb - 1) + w + 1) * 1024;
+  // 1 KiB per key tile and wave: wave w of query block qb keeps 4 qb + w + 1 tiles.  The LARGEST block counts -- not
+  // always the last one: at 129..160 rows the last block has one wave with rows (5 tiles) and the first four (1 + 2 + 3 + 4)
+  int cache = 0;
+  for (int qb = 0; qb < nqb; ++qb) {
+    int c = 0;
+    for (int w = 0; w < 4; ++w)
+      if (4 * qb + w < tmax) c += (4 * qb + w + 1) * 1024;
+    if (c > cache) cache = c;
+  }
   if (tables_out) *tables_out = tables;
   if (cache_out) *cache_out = cache;
   return p.pos_w && p.dtype != HSTU_DTYPE_F32 && p.heads > 1 && p.delta_q == 0 && tmax <= 7 && p.ts_w && p.timestamps &&

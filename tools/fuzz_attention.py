@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Randomised sweep of hstu_mha (forward + backward, every kernel family the dispatcher can pick) against the fp64 oracle:
+
+    python tools/fuzz_attention.py [--cases 300] [--seed 0]
+
+Each case draws dtype, head count, head dims (dqk may differ from dv), max_seq_len from a few regimes (<= 64: the
+one-wave kernels, <= 224: the folded / 4-wave kernels, up to 700: several key blocks), a length distribution (uniform, long
+tail, all full, with empty users), and mask parameters (targets, max_attn_len, contextual_seq_len, min_full_attn_seq_len,
+sort_by_length).  Checks the relative Frobenius error of out, dq, dk, dv against the dtype's gate (the test suite's) and
+that everything is finite; prints one line per failure and a summary with the kernel names exercised.  Not part of the
+test suite (the oracle's per-user loops make it minutes of CPU time); run on the GPU box."""
+import argparse
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from generative_recommenders_amd.ops import _launch  # noqa: E402
+from generative_recommenders_amd.ops.hstu_attention import hstu_mha  # noqa: E402
+from oracle import hstu_oracle as O  # noqa: E402
+
+# relative Frobenius gates.  The test suite's (1.5 x the error measured on large tensors) are averages: a user of ONE row is a
+# handful of roundings and may sit at the format's worst case, half an ulp = 2^-8 (bf16) / 2^-11 (fp16) relative per element
+# -- so the sweep, which draws such users on purpose, gates at 1.5 x that worst case; fp32 as the suite.
+GATE = {torch.float32: 1.5e-6, torch.bfloat16: 1.5 * 2.0 ** -8, torch.float16: 1.5 * 2.0 ** -11}
+
+
+def bias_sweep(a):
+    """research path: random (dtype, heads, head dim, N, lengths, position + time | position-only); out, dq, dk, dv and the
+    two table gradients against the oracle (timestamps kept off the time-bucket boundaries, as the tests do)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_configs_gpu import _timestamps_off_bucket_boundaries
+    import generative_recommenders_amd.research.modeling.sequential.hstu as R
+
+    rng = np.random.default_rng(a.seed)
+    dev = "cuda"
+    fails, kernels = 0, collections.Counter()
+    for case in range(a.cases):
+        dtype = [torch.bfloat16, torch.float16, torch.float32][rng.integers(0, 3)]
+        H = int(rng.integers(1, 7))
+        d = int(rng.choice([8, 16, 32, 64, 128]))
+        regime = rng.integers(0, 3)
+        N = int(rng.integers(3, 65)) if regime == 0 else (int(rng.integers(65, 225)) if regime == 1 else int(rng.integers(225, 400)))
+        B = int(rng.integers(1, 9))
+        lengths = rng.integers(0, N + 1, size=B) if rng.random() < 0.6 else np.where(rng.random(B) < 0.3, N, rng.integers(0, max(N // 3, 1) + 1, size=B))
+        with_ts = bool(rng.random() < 0.8)
+        off = O.complete_cumsum(lengths.astype(np.int64))
+        L = int(off[-1])
+        if L == 0:
+            continue
+        ts = _timestamps_off_bucket_boundaries(rng, B, N)
+        torch.manual_seed(case)
+        bias = (R.RelativeBucketedTimeAndPositionBasedBias(N, 128) if with_ts else R.RelativePositionalBias(N)).to(dev)
+        with torch.no_grad():
+            for prm in bias.parameters():
+                prm.normal_(0, 0.05)
+        pos_w, ts_w, _, _ = bias.bias_params()
+        mk = lambda: torch.from_numpy(rng.standard_normal((L, H * d)) * 0.4).to(dtype)  # noqa: E731
+        q, k, v = mk(), mk(), mk()
+        g = torch.from_numpy(rng.standard_normal((L, H * d))).to(dtype)
+        qd, kd, vd = (t.to(dev).requires_grad_() for t in (q, k, v))
+        desc = f"case {case}: {str(dtype)[6:]} H={H} d={d} N={N} lengths={lengths.tolist()} ts={with_ts}"
+        try:
+            out = R.hstu_rel_bias_attention(H, d, d, qd, kd, vd, torch.from_numpy(off).to(dev), torch.from_numpy(ts).to(dev), N, bias)
+            out.backward(g.to(dev))
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            msg = str(e).split("\n")[0]
+            if "EUNSUPPORTED" in msg or "unsupported" in msg.lower() or "instantiated" in msg:
+                continue
+            fails += 1
+            print("EXCEPTION", desc, "->", msg)
+            continue
+        kernels[_launch.attn_fwd_kernel_name(dtype, d, d, N, heads=H, with_bias=True)] += 1
+        kernels[_launch.attn_bwd_kernel_name(dtype, d, d, N, heads=H, with_bias=True)] += 1
+        pw = pos_w.detach().double().cpu().numpy()
+        tw = None if ts_w is None else ts_w.detach().double().cpu().numpy()
+        q3, k3, v3 = (t.double().numpy().reshape(L, H, d) for t in (q, k, v))
+        ref = O.rel_bias_attention_fwd(N, q3, k3, v3, off, ts if with_ts else None, pw, tw)
+        rq, rk, rv, rpos, rts = O.rel_bias_attention_bwd(N, g.double().numpy().reshape(L, H, d), q3, k3, v3, off, ts if with_ts else None, pw, tw)
+        checks = [("out", out, ref.reshape(L, -1), GATE[dtype]), ("dq", qd.grad, rq.reshape(L, -1), GATE[dtype]), ("dk", kd.grad, rk.reshape(L, -1), GATE[dtype]),
+                  ("dv", vd.grad, rv.reshape(L, -1), GATE[dtype]), ("dpos_w", pos_w.grad, rpos, None)]
+        if with_ts:
+            checks.append(("dts_w", ts_w.grad, rts, None))
+        for name, got, want, gate in checks:
+            gnp = got.detach().double().cpu().numpy()
+            if gate is None:
+                # table gradients: fp32 sums of dS' rounded to the I/O dtype's precision upstream -- a cancelling sum: measure against
+                # the sum of magnitudes' scale (max |want|), 16-bit inputs 2e-2, fp32 2e-4
+                scale = max(np.abs(want).max(), 1e-30)
+                err = np.abs(gnp - want).max() / scale
+                gate = 2e-4 if dtype == torch.float32 else 2e-2
+            else:
+                den = np.linalg.norm(want)
+                err = np.linalg.norm(gnp - want) / den if den > 0 else float(np.abs(gnp).max())
+            if not np.isfinite(gnp).all() or err > gate:
+                fails += 1
+                print("FAIL", desc, f"-> {name}: error {err:.3e} (gate {gate:.1e}), finite={bool(np.isfinite(gnp).all())}")
+    print(f"{a.cases} bias cases, {fails} failures")
+    for kname, n in sorted(kernels.items(), key=lambda kv: -kv[1]):
+        print(f"  {n:4d}  {kname}")
+    sys.exit(1 if fails else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--bias", action="store_true", help="the research path: relative position / time bias (hstu_rel_bias_attention) incl. the table gradients")
+    a = ap.parse_args()
+    if a.bias:
+        return bias_sweep(a)
+    rng = np.random.default_rng(a.seed)
+    dev = "cuda"
+    fails, kernels, worst = 0, collections.Counter(), collections.defaultdict(float)
+    for case in range(a.cases):
+        dtype = [torch.bfloat16, torch.float16, torch.float32][rng.integers(0, 3)]
+        H = int(rng.integers(1, 5))
+        if rng.random() < 0.6:
+            dqk = dv = int(rng.choice([8, 16, 32, 64, 128]))
+        else:
+            dqk, dv = int(rng.choice([16, 32, 64, 128])), int(rng.choice([16, 32, 64, 128]))
+        regime = rng.integers(0, 3)
+        N = int(rng.integers(2, 65)) if regime == 0 else (int(rng.integers(65, 225)) if regime == 1 else int(rng.integers(225, 700)))
+        B = int(rng.integers(1, 7))
+        dist = rng.integers(0, 4)
+        if dist == 0:
+            lengths = rng.integers(0, N + 1, size=B)
+        elif dist == 1:
+            lengths = rng.integers(0, max(N // 3, 1) + 1, size=B)
+            lengths[rng.random(B) < 0.2] = N
+        elif dist == 2:
+            lengths = np.full(B, N)
+        else:
+            lengths = rng.integers(max(N - 5, 0), N + 1, size=B)
+            lengths[0] = 0
+        kw = {}
+        if rng.random() < 0.5:
+            kw["num_targets"] = np.minimum(rng.integers(0, max(N // 4, 1) + 1, size=B), lengths)
+        if rng.random() < 0.35:
+            kw["max_attn_len"] = int(rng.integers(1, N + 1))
+        if rng.random() < 0.25:
+            kw["contextual_seq_len"] = int(rng.integers(1, max(N // 8, 1) + 1))
+        if "max_attn_len" in kw and rng.random() < 0.3:
+            kw["min_full_attn_seq_len"] = int(rng.integers(1, max(N // 4, 1) + 1))
+        sort = bool(rng.random() < 0.3)
+        off = O.complete_cumsum(lengths.astype(np.int64))
+        L = int(off[-1])
+        if L == 0:
+            continue
+        alpha = float(rng.choice([dqk ** -0.5, 1.0 / dqk, 0.37]))
+        mk = lambda d: torch.from_numpy(rng.standard_normal((L, H, d)) * 0.4).to(dtype)  # noqa: E731
+        q, k, v = mk(dqk), mk(dqk), mk(dv)
+        g = torch.from_numpy(rng.standard_normal((L, H, dv))).to(dtype)
+        qd, kd, vd = (t.to(dev).requires_grad_() for t in (q, k, v))
+        tkw = {n: (torch.from_numpy(x.astype(np.int64)).to(dev) if isinstance(x, np.ndarray) else x) for n, x in kw.items()}
+        desc = f"case {case}: {str(dtype)[6:]} H={H} d=({dqk},{dv}) N={N} lengths={lengths.tolist()} {kw} sort={sort} alpha={alpha:.4f}"
+        try:
+            out = hstu_mha(N, alpha, qd, kd, vd, torch.from_numpy(off).to(dev), sort_by_length=sort, **tkw)
+            out.backward(g.to(dev))
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            msg = str(e).split("\n")[0]
+            if "not instantiated" in msg or "EUNSUPPORTED" in msg or "unsupported" in msg.lower():
+                continue                 # a documented refusal
+            fails += 1
+            print("EXCEPTION", desc, "->", msg)
+            continue
+        with_t, w, c = kw.get("num_targets") is not None, kw.get("max_attn_len", 0), kw.get("contextual_seq_len", 0)
+        kernels[_launch.attn_fwd_kernel_name(dtype, dqk, dv, N, heads=H, alpha=alpha, max_attn_len=w, contextual_seq_len=c)] += 1
+        kernels[_launch.attn_bwd_kernel_name(dtype, dqk, dv, N, heads=H, alpha=alpha, max_attn_len=w, contextual_seq_len=c)] += 1
+        q6, k6, v6, g6 = (t.double().numpy() for t in (q, k, v, g))
+        ref = O.hstu_mha_fwd(N, alpha, q6, k6, v6, off, **kw)
+        rq, rk, rv = O.hstu_mha_bwd(N, alpha, g6, q6, k6, v6, off, **kw)
+        for name, got, want in (("out", out, ref), ("dq", qd.grad, rq), ("dk", kd.grad, rk), ("dv", vd.grad, rv)):
+            gnp = got.detach().double().cpu().numpy()
+            den = np.linalg.norm(want)
+            rel = np.linalg.norm(gnp - want) / den if den > 0 else float(np.abs(gnp).max())
+            worst[str(dtype)[6:]] = max(worst[str(dtype)[6:]], rel)
+            if not np.isfinite(gnp).all() or rel > GATE[dtype]:
+                fails += 1
+                print("FAIL", desc, f"-> {name}: rel Frobenius {rel:.3e} (gate {GATE[dtype]}), finite={bool(np.isfinite(gnp).all())}, targets={with_t}")
+    print(f"{a.cases} cases, {fails} failures; worst relative Frobenius error by dtype: " + ", ".join(f"{k} {v:.2e}" for k, v in sorted(worst.items())))
+    for kname, n in sorted(kernels.items(), key=lambda kv: -kv[1]):
+        print(f"  {n:4d}  {kname}")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
