@@ -110,6 +110,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", action="store_true", help="hundreds to thousands of users per case (persistent workgroups walk many problems), N <= 224")
     ap.add_argument("--bias", action="store_true", help="the research path: relative position / time bias (hstu_rel_bias_attention) incl. the table gradients")
     a = ap.parse_args()
     if a.bias:
@@ -127,6 +128,11 @@ def main():
         regime = rng.integers(0, 3)
         N = int(rng.integers(2, 65)) if regime == 0 else (int(rng.integers(65, 225)) if regime == 1 else int(rng.integers(225, 700)))
         B = int(rng.integers(1, 7))
+        if a.big:
+            N = int(rng.integers(2, 65)) if regime == 0 else int(rng.integers(65, 225))
+            B = int(rng.integers(300, 2500))
+            if rng.random() < 0.7:
+                dqk = dv = int(rng.choice([16, 64, 128]))
         dist = rng.integers(0, 4)
         if dist == 0:
             lengths = rng.integers(0, N + 1, size=B)
