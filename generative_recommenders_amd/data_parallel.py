@@ -143,6 +143,7 @@ class GradientAllReducer:
                 self.buckets.append(cur)
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self.overlap = overlap
+        self._sync = True
         self._pending: List[int] = [0] * len(self.buckets)
         self._work: List[Optional[object]] = [None] * len(self.buckets)
         self._hooks = []
@@ -171,8 +172,27 @@ class GradientAllReducer:
             self._flat[bi] = flat
         return flat
 
+    def no_sync(self):
+        """context manager for gradient accumulation: backward passes inside it only accumulate locally (into the bucket
+        buffers: p.grad becomes a view of its bucket and later passes add in place); the first backward OUTSIDE launches the
+        collectives on the accumulated sums (the role of DDP.no_sync())."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = old
+
+        return ctx()
+
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         bi, o = self._slot[id(p)]
+        if self._work[bi] is not None:
+            raise RuntimeError("GradientAllReducer: a gradient arrived for a bucket whose all-reduce is already in flight -- call "
+                               "reduce() after every backward, or wrap the extra backward passes in no_sync()")
         flat = self._bucket_flat(bi, p.grad)
         view = flat[o : o + p.numel()].view_as(p)
         if p.grad.data_ptr() != view.data_ptr():
@@ -187,7 +207,9 @@ class GradientAllReducer:
                 for q, v in staged:
                     q.grad = v         # the reduced values appear in p.grad without a copy back
                 self._staged[bi] = []
-            if dist.is_initialized() and dist.get_world_size() > 1:
+            if not self._sync:
+                self._pending[bi] = len(self.buckets[bi])        # accumulate only: count the next backward from the top
+            elif dist.is_initialized() and dist.get_world_size() > 1:
                 self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def remove_hooks(self) -> None:

@@ -79,6 +79,30 @@ def _worker_overlap(rank, world, port, out_dir):
         ref(data).pow(2).sum().backward()
         for p, q in zip(model.parameters(), ref.parameters()):
             torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+    # gradient accumulation: two micro-batches, the first under no_sync() -- one collective per bucket, on the sums
+    data = torch.randn(8, 8, generator=g)
+    for p in model.parameters():
+        p.grad = None
+    half = len(mine) // 2
+    with red.no_sync():
+        model(data[mine[:half]]).pow(2).sum().backward()
+    model(data[mine[half:]]).pow(2).sum().backward()
+    red.reduce()
+    for p in ref.parameters():
+        p.grad = None
+    ref(data).pow(2).sum().backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+    # a second backward without reduce() / no_sync() is refused instead of reducing half a gradient
+    for p in model.parameters():
+        p.grad = None
+    model(data[mine]).pow(2).sum().backward()
+    try:
+        model(data[mine]).pow(2).sum().backward()
+        raise AssertionError("expected the reducer to refuse a second backward before reduce()")
+    except RuntimeError as e:
+        assert "no_sync" in str(e)
+    red.reduce()
     info = dp.describe_ranks()
     assert info["backend"] == "gloo" and [r["rank"] for r in info["ranks"]] == list(range(world))
     dist.barrier()
