@@ -28,6 +28,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # hosts whose driver only supports dmabuf IPC: without it RCCL's buffer exchange fails in hipIpcGetMemHandle
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             # HSTU_DIST_BACKEND=gloo: rehearse the multi-rank flow where there are fewer GPUs than ranks (RCCL refuses two
             # ranks on one device; gloo moves the few control tensors through the host)
