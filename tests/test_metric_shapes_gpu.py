@@ -9,6 +9,8 @@ targets).  The fixture's inputs are bf16-representable, so the same values go to
 Gates (16-bit): 1.5 x the errors measured on MI355X (profiles/r02_parity_errors.md).  Rounding the exact answer of
 normally distributed values to bf16 alone is 1.66e-3 relative Frobenius (fp16: 2.08e-4)."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -71,10 +73,13 @@ def test_16bit_kernels_against_exact_and_rounded_reference(idx, dtype):
     assert not failures, f"gates {gate_exact} (exact reference) / {gate_rounded} (rounded reference): {failures}"
 
 
-def test_the_headline_backward_is_the_folded_kernel():
-    """what bench.py times: ask the library which backward it dispatches for the metric shape"""
+def test_the_headline_backward_is_the_wide_kernel():
+    """what bench.py times: ask the library which backward it dispatches for the metric shape (HSTU_BWD_WIDE=0: the folded
+    kernel of rounds 1-3)"""
     from generative_recommenders_amd.ops import _launch
 
-    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 200).startswith("hstu_attn_bwd_fold_kernel")
+    want = "hstu_attn_bwd_fold_kernel" if os.environ.get("HSTU_BWD_WIDE", "1")[:1] == "0" else "hstu_attn_bwd_wide_kernel"
+    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 200).startswith(want)
+    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 64, 64, 200).startswith("hstu_attn_bwd_quad_kernel")
     assert _launch.attn_bwd_kernel_name(torch.float32, 128, 128, 200).startswith("hstu_attn_bwd_kernel")
     assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 256).startswith("hstu_attn_bwd_kernel")
