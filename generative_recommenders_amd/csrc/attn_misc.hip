@@ -36,7 +36,14 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
 // head dim 128 of the folded shapes: the wide schedule (four waves, one per SIMD, 512 registers each)
 bool attn_bwd_wide_applicable(const HstuAttnBwdParams& bp) {
   static const bool enabled = [] { const char* e = getenv("HSTU_BWD_WIDE"); return !(e && e[0] == '0'); }();
-  return enabled && attn_bwd_fold_applicable(bp) && bp.fwd.dqk == 128 && bp.fwd.dv == 128;
+  if (!enabled || !attn_bwd_fold_applicable(bp) || bp.fwd.dqk != 128 || bp.fwd.dv != 128) return false;
+  // its LDS-DMA source addresses are a scalar base + a 32-bit offset (24-bit multiply): row strides below 16 MiB, a user's rows
+  // within 4 GiB of its first row; its register -> memory stores go through buffer descriptors of at most 2 GiB per tile
+  const HstuAttnParams& p = bp.fwd;
+  const int64_t rows = 32 * ((p.max_seq_len + 31) / 32);
+  for (int64_t rs : {p.q_row_stride, p.k_row_stride, p.v_row_stride, bp.do_row_stride, bp.dq_row_stride, bp.dk_row_stride, bp.dv_row_stride})
+    if (rs * 2 >= (1 << 24) || rows * rs * 2 >= (1LL << 31)) return false;
+  return true;
 }
 
 bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {

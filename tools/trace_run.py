@@ -45,7 +45,7 @@ def dump(t, names, waves):
 print("===== BACKWARD (workgroup 4096): cycles since the first wave's start; one column per wave")
 t = trace.cpu().view(8, 128, 2).numpy()
 names = {1: "start", 2: "prologue dma issued", 10: "TOP barrier passed", 11: "S,dP done", 12: "elementwise done",
-         13: "pair done", 14: "-", 15: "barrier1 passed", 16: "dQ gemm done", 17: "dQ stored",
+         13: "pairs done", 14: "pair done", 15: "barrier1 passed", 16: "dQ gemm done", 17: "dQ stored",
          18: "stage dma+copy-out issued", 19: "dq setup done", 20: "loop done", 21: "end", 22: "dump barrier passed", 23: "dV parked", 24: "final tiles parked"}
 t0 = min(int(t[w, 0, 1]) for w in range(8) if t[w, 0, 0])
 # waves skip marks 11/12 when they have no pair: align rows by (tag, occurrence)
