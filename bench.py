@@ -29,6 +29,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with the extra obje
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the first torch.cuda call (dmabuf-only IPC hosts: RCCL needs it)
 import socket
 import statistics
 import sys

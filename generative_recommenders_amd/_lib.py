@@ -107,8 +107,9 @@ SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
-def build(verbose: bool = False) -> str:
-    """Compile libhstu_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(verbose: bool = False, torch_ops_optional: bool = False) -> str:
+    """Compile libhstu_hip.so and libhstu_torch_ops.so in-tree for gfx950 (hipcc cross-compiles without a GPU).  A failure of
+    either is an error; ``torch_ops_optional=True`` (C-ABI-only consumers) downgrades the second one to a warning."""
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", str(os.cpu_count() or 4)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
@@ -119,6 +120,8 @@ def build(verbose: bool = False) -> str:
     try:
         build_torch_ops(verbose)
     except HstuLibraryError as e:   # the C-ABI library is usable without the torch.ops.hstu registration
+        if not torch_ops_optional:
+            raise
         import warnings
         warnings.warn(f"libhstu_hip.so built, but {e}; torch.ops.hstu.* will not be available")
     return LIB_PATH

@@ -33,9 +33,11 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 
-// head dim 128 of the folded shapes: the wide schedule (four waves, one per SIMD, 512 registers each)
+// head dim 128 of the folded shapes: the wide schedule (four waves, one per SIMD, 512 registers each).  Round 4's structural
+// experiment: correct (same tests as the folded kernel) and measured SLOWER (3.28-3.85 ms against 2.99-3.07 ms on the metric
+// shape: docs/EXPERIMENTS.md Part R4), so it is opt-in: HSTU_BWD_WIDE=1.
 bool attn_bwd_wide_applicable(const HstuAttnBwdParams& bp) {
-  static const bool enabled = [] { const char* e = getenv("HSTU_BWD_WIDE"); return !(e && e[0] == '0'); }();
+  static const bool enabled = [] { const char* e = getenv("HSTU_BWD_WIDE"); return e && e[0] == '1'; }();
   if (!enabled || !attn_bwd_fold_applicable(bp) || bp.fwd.dqk != 128 || bp.fwd.dv != 128) return false;
   // its LDS-DMA source addresses are a scalar base + a 32-bit offset (24-bit multiply): row strides below 16 MiB, a user's rows
   // within 4 GiB of its first row; its register -> memory stores go through buffer descriptors of at most 2 GiB per tile

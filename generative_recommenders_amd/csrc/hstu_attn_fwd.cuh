@@ -14,8 +14,9 @@
 //     P^T  = silu(alpha S^T) * scale * M      in the MFMA C layout == the B layout
 //                                              of the next MFMA (no shuffles, no LDS)
 //     O^T += V_j^T P^T     A = V tile through the LDS transpose read
-// K/V tiles of 32 keys stream through a 2-stage LDS ring; the global loads of
-// tile t+1 are issued before the math of tile t and written to LDS after it.
+// K/V tiles of 32 keys stream through a 3-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4 through inline asm,
+// source addresses from a 2-register per-lane plan): two tiles in flight per workgroup, one raw s_barrier per tile with a
+// counted s_waitcnt vmcnt; three workgroups per CU (165 VGPRs).  (2 stages when a stage exceeds 16 KiB: FwdCfg.)
 // HSTU has no softmax, so there is no running max / rescale: tiles are independent.
 #pragma once
 #include "hstu_common.cuh"

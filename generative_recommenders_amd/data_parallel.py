@@ -28,8 +28,6 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # hosts whose driver only supports dmabuf IPC: without it RCCL's buffer exchange fails in hipIpcGetMemHandle
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             # HSTU_DIST_BACKEND=gloo: rehearse the multi-rank flow where there are fewer GPUs than ranks (RCCL refuses two
             # ranks on one device; gloo moves the few control tensors through the host)
@@ -125,10 +123,14 @@ class GradientAllReducer:
         self.average = average
         self.buckets: List[List[torch.nn.Parameter]] = []
         if buckets is not None:
+            # a bucket is ONE flat buffer: parameters of different dtypes (or devices) of a group get buckets of their own,
+            # in first-appearance order (as the byte-size split below does)
             for grp in buckets:
-                cur = [p for p in grp if p.requires_grad]
-                if cur:
-                    self.buckets.append(cur)
+                by_kind = {}
+                for p in grp:
+                    if p.requires_grad:
+                        by_kind.setdefault((p.dtype, p.device), []).append(p)
+                self.buckets.extend(by_kind.values())
             self.params = [p for b in self.buckets for p in b]
         else:
             self.params = [p for p in params if p.requires_grad]
@@ -167,10 +169,15 @@ class GradientAllReducer:
         self._staged = [[] for _ in self.buckets]
 
     def _bucket_flat(self, bi: int, like: torch.Tensor) -> torch.Tensor:
-        n = sum(p.numel() for p in self.buckets[bi])
+        """the bucket's flat buffer: allocated once, sized and typed from its parameters (a gradient of another dtype is
+        refused: re-allocating would orphan the views already handed out as p.grad)"""
+        bucket = self.buckets[bi]
+        if like.dtype != bucket[0].dtype or like.device != bucket[0].device:
+            raise RuntimeError(f"GradientAllReducer: gradient of dtype {like.dtype} on {like.device} for a bucket of "
+                               f"{bucket[0].dtype} parameters on {bucket[0].device}")
         flat = self._flat[bi]
-        if flat is None or flat.numel() != n or flat.device != like.device or flat.dtype != like.dtype:
-            flat = torch.empty(n, dtype=like.dtype, device=like.device)
+        if flat is None:
+            flat = torch.empty(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=bucket[0].device)
             self._flat[bi] = flat
         return flat
 
@@ -222,29 +229,51 @@ class GradientAllReducer:
     def reduce(self) -> None:
         if self.overlap:
             world = dist.get_world_size() if dist.is_initialized() else 1
+            # Collectives pair up across ranks by ISSUE ORDER.  The hooks launch a bucket when its last gradient arrives, i.e. in
+            # backward order, identical on every rank as long as every parameter gets a gradient everywhere.  A bucket that is
+            # incomplete on this rank (parameters unused in this step) is reduced here -- zeros for the missing gradients --
+            # in bucket order AFTER the hook-launched ones; ranks on which the same bucket was complete launched it from a
+            # hook, which would pair different buffers: so the set of incomplete buckets must be the same on all ranks (the
+            # model's parameter usage may not depend on the rank's data).  That precondition is checked, not assumed: one
+            # tiny all-reduce of the bucket-state bitmap per step, only in steps that have an incomplete bucket anywhere.
+            late = [bi for bi, w in enumerate(self._work) if w is None and self._pending[bi] != 0]
             for bi, work in enumerate(self._work):
                 if work is not None:
                     work.wait()
                     if self.average:
                         self._flat[bi].div_(world)
-                elif self._pending[bi] != len(self.buckets[bi]) and self._pending[bi] != 0:
-                    # some parameters of the bucket got no gradient this step: reduce what is there (zeros for the rest)
-                    flat = self._flat[bi]
-                    staged = self._staged[bi]
-                    if staged:
-                        torch._foreach_copy_([v for _, v in staged], [q.grad for q, _ in staged])
-                        for q, v in staged:
-                            q.grad = v
-                    if world == 1:
-                        continue
-                    for p in self.buckets[bi]:
-                        if p.grad is None:
-                            b2, o = self._slot[id(p)]
-                            flat[o : o + p.numel()].zero_()
-                            p.grad = flat[o : o + p.numel()].view_as(p)
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                    if self.average:
-                        flat.div_(world)
+            if world > 1 and self._sync:
+                ref = self.buckets[0][0]
+                state = torch.zeros(len(self.buckets) + 1, dtype=torch.int32, device=ref.device)
+                for bi in late:
+                    state[bi] = 1
+                state[-1] = 1 if late else 0
+                # (every rank takes part: a rank without late buckets cannot know whether another one has some)
+                mx = state.clone()
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                if int(mx[-1]) and not torch.equal(mx[:-1], state[:-1]):
+                    raise RuntimeError("GradientAllReducer(overlap=True): the buckets with parameters that received no gradient differ "
+                                       "between ranks -- their collectives would pair different buffers.  Parameter usage must not "
+                                       "depend on a rank's data (or use overlap=False).")
+            for bi in late:
+                staged = self._staged[bi]
+                if staged:
+                    flat = self._bucket_flat(bi, staged[0][0].grad)
+                    torch._foreach_copy_([v for _, v in staged], [q.grad for q, _ in staged])
+                    for q, v in staged:
+                        q.grad = v
+                    self._staged[bi] = []
+                if world == 1 or not self._sync:
+                    continue
+                flat = self._bucket_flat(bi, self.buckets[bi][0])
+                for p in self.buckets[bi]:
+                    if p.grad is None:
+                        b2, o = self._slot[id(p)]
+                        flat[o : o + p.numel()].zero_()
+                        p.grad = flat[o : o + p.numel()].view_as(p)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                if self.average:
+                    flat.div_(world)
             self._reset()
             return
         if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -10,6 +10,7 @@ SURVEY.md App. F): results are identical whichever recompute flags are chosen.
 """
 
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -37,7 +38,14 @@ def hstu_compute_uqvk(
     del kernel
     norm_weight, norm_bias, uvqk_weight, uvqk_bias = (t.to(x.dtype) for t in (norm_weight, norm_bias, uvqk_weight, uvqk_bias))
     normed_x = layer_norm(x, weight=norm_weight, bias=norm_bias, eps=norm_eps)
-    uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)        # (autograd's own node: the reference layout)
+    # (autograd's own nodes.  The same GEMM kernel as the fused layer's -- linear() on a K-contiguous weight -- so that the
+    # K / V rows a delta call appends to a cache are bit-identical to the ones the prefill wrote)
+    if _UVQK_LINEAR and normed_x.is_cuda:
+        tracked = torch.is_grad_enabled() and uvqk_weight.requires_grad
+        wt = uvqk_weight.t().contiguous() if tracked else _kmajor(uvqk_weight, normed_x.dtype)
+        uvqk = torch.nn.functional.linear(normed_x, wt.to(normed_x.dtype), uvqk_bias.to(normed_x.dtype))
+    else:
+        uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
     u, v, q, k = torch.split(
         uvqk, [hidden_dim * num_heads, hidden_dim * num_heads, attn_dim * num_heads, attn_dim * num_heads], dim=1
     )
@@ -68,15 +76,41 @@ def draw_dropout_seed() -> int:
 
 # The UVQK projection as ``linear(x, W^T-copy, b)``: hipBLASLt's kernels for a K-contiguous weight run this shape (K = 512, N =
 # 2048) at 797 TFLOP/s against 737 for ``addmm(b, x, W)`` with the reference's (in, out) layout (tools/bench_gemm_layout.py,
-# profiles/r03_gemm_layout.txt).  The transposed copy is a 1 M-element pass next to the parameter cast; HSTU_UVQK_LINEAR=0
-# keeps addmm.
+# profiles/r03_gemm_layout.txt).  The transposed copy IS the parameter cast (one pass, cached per parameter version: _kmajor) and
+# it is what backward keeps: the data gradient is mm(duvqk, W^T-copy) without another transpose.  HSTU_UVQK_LINEAR=0 keeps addmm.
 _UVQK_LINEAR = os.environ.get("HSTU_UVQK_LINEAR", "1") != "0"
 
 
-def _uvqk_gemm(normed_x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    if _UVQK_LINEAR and normed_x.is_cuda:
-        return torch.nn.functional.linear(normed_x, weight.t().contiguous(), bias)
-    return torch.addmm(bias, normed_x, weight)
+_KMAJOR_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _kmajor(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """The (in, out) projection weight as a K-contiguous (out, in) copy in the activations' dtype: ONE transposing, casting
+    pass, cached per parameter until the parameter changes (its version counter: an optimizer step, a load_state_dict) --
+    forward, the recompute in backward and every inference call of an unchanged weight share one copy."""
+    hit = _KMAJOR_CACHE.get(weight)
+    key = (weight._version, dtype, weight.data_ptr())
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wt = torch.empty((weight.shape[1], weight.shape[0]), dtype=dtype, device=weight.device)
+    wt.copy_(weight.detach().t())
+    _KMAJOR_CACHE[weight] = (key, wt)
+    return wt
+
+
+def _uvqk_prepare(weight: torch.Tensor, dtype: torch.dtype):
+    """(tensor, kmajor): what the fused nodes multiply by and save for backward"""
+    if _UVQK_LINEAR and weight.is_cuda:
+        return _kmajor(weight, dtype), True
+    return _cast(weight, dtype), False
+
+
+def _uvqk_gemm(normed_x: torch.Tensor, w: torch.Tensor, kmajor: bool, bias: torch.Tensor) -> torch.Tensor:
+    return torch.nn.functional.linear(normed_x, w, bias) if kmajor else torch.addmm(bias, normed_x, w)
+
+
+def _uvqk_dgrad(duvqk: torch.Tensor, w: torch.Tensor, kmajor: bool) -> torch.Tensor:
+    return torch.mm(duvqk, w) if kmajor else torch.mm(duvqk, w.t())
 
 
 def _cast(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -184,10 +218,10 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                 num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
                 recompute_uvqk, recompute_normed_x, user_order=None):
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
-        norm_weight, norm_bias, uvqk_weight, uvqk_bias = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_weight,
-                                                                                       uvqk_bias))
+        norm_weight, norm_bias, uvqk_bias = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_bias))
+        uvqk_weight, ctx.kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
         normed_x, mean, rstd = _launch.layer_norm_fwd(x, norm_weight, norm_bias, norm_eps)
-        uvqk = _uvqk_gemm(normed_x, uvqk_weight, uvqk_bias)
+        uvqk = _uvqk_gemm(normed_x, uvqk_weight, ctx.kmajor, uvqk_bias)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
         u_pre = uvqk[:, :hv]
         v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
@@ -224,7 +258,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         if normed_x is None:
             normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, eps)
         if uvqk is None:
-            uvqk = _uvqk_gemm(normed_x, W, beta)
+            uvqk = _uvqk_gemm(normed_x, W, ctx.kmajor, beta)
         hv, ha = Hd * H, A * H
         v = uvqk[:, hv : 2 * hv].view(-1, H, Hd)
         q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
@@ -237,7 +271,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                          dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         _launch.silu_bwd(du, uvqk[:, :hv], din=duvqk[:, :hv])
         nw_dtype, nb_dtype, w_dtype, beta_dtype = ctx.param_dtypes
-        d_normed = torch.mm(duvqk, W.t())
+        d_normed = _uvqk_dgrad(duvqk, W, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=w_dtype)
         dbeta = duvqk.sum(dim=0, dtype=torch.float32 if beta_dtype == torch.float32 else None)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
@@ -265,10 +299,11 @@ class _STULayerFunction(torch.autograd.Function):
                 in_eps, out_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
                 recompute_uvqk, recompute_normed_x, recompute_y, concat_ux, group_norm, dropout_ratio, seed, user_order):
         ctx.param_dtypes = tuple(t.dtype for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
-        in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight = (
-            _cast(t, x.dtype) for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
+        in_nw, in_nb, uvqk_bias, out_nw, out_nb, output_weight = (
+            _cast(t, x.dtype) for t in (in_nw, in_nb, uvqk_bias, out_nw, out_nb, output_weight))
+        uvqk_weight, ctx.kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
         normed_x, mean, rstd = _launch.layer_norm_fwd(x, in_nw, in_nb, in_eps)
-        uvqk = _uvqk_gemm(normed_x, uvqk_weight, uvqk_bias)
+        uvqk = _uvqk_gemm(normed_x, uvqk_weight, ctx.kmajor, uvqk_bias)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
         v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
         q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, num_heads, attn_dim)
@@ -306,7 +341,7 @@ class _STULayerFunction(torch.autograd.Function):
         if normed_x is None:
             normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, in_eps)
         if uvqk is None:
-            uvqk = _uvqk_gemm(normed_x, W, beta)
+            uvqk = _uvqk_gemm(normed_x, W, ctx.kmajor, beta)
         hv, ha = Hd * H, A * H
         u_pre = uvqk[:, :hv]
         if y is None:
@@ -332,7 +367,7 @@ class _STULayerFunction(torch.autograd.Function):
         _launch.attn_bwd(dattn.view(-1, H, Hd), q, k, v, seq_offsets, num_targets, N, alpha, 1.0 / N, w, c, 0,
                          dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         # ---- projections and the input norm (+ the residual's gradient, inside the kernel)
-        d_normed = torch.mm(duvqk, W.t())
+        d_normed = _uvqk_dgrad(duvqk, W, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
         dbeta = duvqk.sum(dim=0, dtype=torch.float32 if dt[3] == torch.float32 else None)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd, dresidual=dout)

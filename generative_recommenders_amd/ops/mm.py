@@ -49,7 +49,9 @@ def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor, out_dtype: Optional[torch.
     tiles = -(-K // 256) * -(-N // 256)
     S = min(_SPLIT_SLABS, L // _MIN_SLAB_ROWS, max(1, 256 // tiles), max(1, (64 << 20) // (K * N * 4)))
     out_dtype = out_dtype or x.dtype
-    if not x.is_cuda or S <= 1:
+    if not x.is_cuda:
+        raise RuntimeError("weight_grad_mm: CPU tensors are not supported (one backend, no fallback: DESIGN.md 1)")
+    if S <= 1:
         return torch.mm(x.t(), dy).to(out_dtype)
     slab = (L // S) // 64 * 64
     main = slab * S

@@ -110,6 +110,52 @@ def _worker_overlap(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_mixed(rank, world, port, out_dir):
+    """an explicit bucket of mixed dtypes (fp32 / bf16 / fp32) is split by dtype: every gradient is reduced (round 3's reducer
+    re-allocated the flat buffer at the first bf16 gradient and left the fp32 ones out of the collective); a bucket with a
+    parameter that gets no gradient is reduced in reduce(), on every rank alike"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from generative_recommenders_amd import data_parallel as dp
+
+    dp.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(4, 3))
+    b = torch.nn.Parameter(torch.randn(3, 5).to(torch.bfloat16))
+    c = torch.nn.Parameter(torch.randn(5))
+    unused = torch.nn.Parameter(torch.randn(2))
+    red = dp.GradientAllReducer(None, buckets=[[a, b, c], [unused, torch.nn.Parameter(torch.randn(2))]], overlap=True, average=False)
+    assert [len(bk) for bk in red.buckets] == [2, 1, 2] and red.buckets[1][0] is b
+    used2 = red.buckets[2][1]
+    x = torch.full((2, 4), float(rank + 1))
+    y = ((x @ a).to(torch.bfloat16) @ b).float() + c
+    (y.sum() + used2.sum() * (rank + 1)).backward()
+    red.reduce()
+    # the same on one process with both ranks' inputs
+    tot = {}
+    for r in range(world):
+        aa, bb, cc = (t.detach().clone().requires_grad_() for t in (a, b, c))
+        xx = torch.full((2, 4), float(r + 1))
+        (((xx @ aa).to(torch.bfloat16) @ bb).float() + cc).sum().backward()
+        for n, t in (("a", aa), ("b", bb), ("c", cc)):
+            tot[n] = t.grad.float() + tot.get(n, 0)
+    torch.testing.assert_close(a.grad, tot["a"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(b.grad.float(), tot["b"], rtol=2e-2, atol=1e-2)
+    torch.testing.assert_close(c.grad, tot["c"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(used2.grad, torch.full((2,), float(sum(range(1, world + 1)))))
+    assert unused.grad is not None and float(unused.grad.abs().sum()) == 0.0
+    dist.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_mixed_dtype_bucket_and_unused_parameter(tmp_path):
+    port = 29650 + (os.getpid() % 100)
+    mp.spawn(_worker_mixed, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
 def test_gloo_world2_overlapped_per_layer_buckets(tmp_path):
     port = 29850 + (os.getpid() % 100)
     mp.spawn(_worker_overlap, args=(2, port, str(tmp_path)), nprocs=2, join=True)

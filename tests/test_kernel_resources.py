@@ -92,3 +92,27 @@ def test_hot_kernels_stay_under_their_occupancy_limits():
     assert fwd[0]["vgpr"] <= 168, fwd            # 3 waves per SIMD (512 / 3, allocation granule 8)
     assert fold[0]["vgpr"] <= 256, fold          # 2 waves per SIMD
     assert fold64[0]["vgpr"] <= 256, fold64
+
+
+def test_wide_backward_owns_the_accumulator_file_and_passes_the_asm_lint():
+    """round 4's four-wave backward (opt-in: HSTU_BWD_WIDE=1) issues every MFMA through inline asm and owns all 256 AGPRs by
+    literal register names: one wave per SIMD (<= 512 registers), no spill, and the checks of tools/lint_asm_mfma.py on the
+    code hipcc emits (no compiler instruction in the accumulator file, none touching a chain's accumulators inside the chain,
+    two wait states in front of every MFMA)."""
+    ks = _kernels()
+    wide = [v for k, v in ks.items() if "hstu_attn_bwd_wide_kernel" in k]
+    assert len(wide) == 2, list(ks)                # bf16, f16
+    for v in wide:
+        assert v["vgpr"] <= 512 and v["spill"] == 0 and v["scratch"] == 0, v
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("lint_asm_mfma", os.path.join(ROOT, "tools", "lint_asm_mfma.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    csrc = os.path.join(ROOT, "generative_recommenders_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "wide.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I.", "-I../../include",
+                        "--cuda-device-only", "-S", "attn_wide_bf16.hip", "-o", out], cwd=csrc, check=True, stderr=subprocess.DEVNULL)
+        findings, n = lint.lint(out, "hstu_attn_bwd_wide")
+    assert n > 200 and not findings, findings[:10]

@@ -7,8 +7,9 @@ Each case draws dtype, head count, head dims (dqk may differ from dv), max_seq_l
 one-wave kernels, <= 224: the folded / 4-wave kernels, up to 700: several key blocks), a length distribution (uniform, long
 tail, all full, with empty users), and mask parameters (targets, max_attn_len, contextual_seq_len, min_full_attn_seq_len,
 sort_by_length).  Checks the relative Frobenius error of out, dq, dk, dv against the dtype's gate (the test suite's) and
-that everything is finite; prints one line per failure and a summary with the kernel names exercised.  Not part of the
-test suite (the oracle's per-user loops make it minutes of CPU time); run on the GPU box."""
+that everything is finite; prints one line per failure and a summary with the kernel names exercised.  The full sweeps are
+not part of the test suite (the oracle's per-user loops make them minutes of CPU time); tests/test_fuzz_gpu.py runs a seeded
+slice of each (mha_sweep / bias_sweep with force_n = the tile-boundary lengths)."""
 import argparse
 import collections
 import os
@@ -29,22 +30,24 @@ from oracle import hstu_oracle as O  # noqa: E402
 GATE = {torch.float32: 1.5e-6, torch.bfloat16: 1.5 * 2.0 ** -8, torch.float16: 1.5 * 2.0 ** -11}
 
 
-def bias_sweep(a):
+def bias_sweep(cases, seed, force_n=None, exit_process=True):
     """research path: random (dtype, heads, head dim, N, lengths, position + time | position-only); out, dq, dk, dv and the
     two table gradients against the oracle (timestamps kept off the time-bucket boundaries, as the tests do)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_configs_gpu import _timestamps_off_bucket_boundaries
     import generative_recommenders_amd.research.modeling.sequential.hstu as R
 
-    rng = np.random.default_rng(a.seed)
+    rng = np.random.default_rng(seed)
     dev = "cuda"
     fails, kernels = 0, collections.Counter()
-    for case in range(a.cases):
+    for case in range(cases):
         dtype = [torch.bfloat16, torch.float16, torch.float32][rng.integers(0, 3)]
         H = int(rng.integers(1, 7))
         d = int(rng.choice([8, 16, 32, 64, 128]))
         regime = rng.integers(0, 3)
         N = int(rng.integers(3, 65)) if regime == 0 else (int(rng.integers(65, 225)) if regime == 1 else int(rng.integers(225, 400)))
+        if force_n:                      # (the test suite's slice: the tile-boundary lengths, more than one head)
+            N, H = int(force_n[case % len(force_n)]), max(H, 2)
         B = int(rng.integers(1, 9))
         lengths = rng.integers(0, N + 1, size=B) if rng.random() < 0.6 else np.where(rng.random(B) < 0.3, N, rng.integers(0, max(N // 3, 1) + 1, size=B))
         with_ts = bool(rng.random() < 0.8)
@@ -100,10 +103,12 @@ def bias_sweep(a):
             if not np.isfinite(gnp).all() or err > gate:
                 fails += 1
                 print("FAIL", desc, f"-> {name}: error {err:.3e} (gate {gate:.1e}), finite={bool(np.isfinite(gnp).all())}")
-    print(f"{a.cases} bias cases, {fails} failures")
+    print(f"{cases} bias cases, {fails} failures")
     for kname, n in sorted(kernels.items(), key=lambda kv: -kv[1]):
         print(f"  {n:4d}  {kname}")
-    sys.exit(1 if fails else 0)
+    if exit_process:
+        sys.exit(1 if fails else 0)
+    return fails, kernels
 
 
 def main():
@@ -114,7 +119,16 @@ def main():
     ap.add_argument("--bias", action="store_true", help="the research path: relative position / time bias (hstu_rel_bias_attention) incl. the table gradients")
     a = ap.parse_args()
     if a.bias:
-        return bias_sweep(a)
+        return bias_sweep(a.cases, a.seed)
+    return mha_sweep(a.cases, a.seed, big=a.big)
+
+
+def mha_sweep(cases, seed, big=False, force_n=None, exit_process=True, force_d=None):
+    """ops path (hstu_mha forward + backward); `force_n`: max_seq_len of case i = force_n[i % len], at least two heads"""
+    class _A:
+        pass
+    a = _A()
+    a.cases, a.seed, a.big = cases, seed, big
     rng = np.random.default_rng(a.seed)
     dev = "cuda"
     fails, kernels, worst = 0, collections.Counter(), collections.defaultdict(float)
@@ -133,6 +147,12 @@ def main():
             B = int(rng.integers(300, 2500))
             if rng.random() < 0.7:
                 dqk = dv = int(rng.choice([16, 64, 128]))
+        if force_n:
+            N, H = int(force_n[case % len(force_n)]), max(H, 2)
+        if force_d:
+            dqk = dv = int(force_d)
+            if dtype == torch.float32:
+                dtype = torch.bfloat16
         dist = rng.integers(0, 4)
         if dist == 0:
             lengths = rng.integers(0, N + 1, size=B)
@@ -193,7 +213,9 @@ def main():
     print(f"{a.cases} cases, {fails} failures; worst relative Frobenius error by dtype: " + ", ".join(f"{k} {v:.2e}" for k, v in sorted(worst.items())))
     for kname, n in sorted(kernels.items(), key=lambda kv: -kv[1]):
         print(f"  {n:4d}  {kname}")
-    sys.exit(1 if fails else 0)
+    if exit_process:
+        sys.exit(1 if fails else 0)
+    return fails, kernels
 
 
 if __name__ == "__main__":
