@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime ou
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSTU_HIP_LIBRARY overrides the in-tree build (A/B measurements of kernel variants, packaged installs)
 LIB_PATH = os.environ.get("HSTU_HIP_LIBRARY") or os.path.join(_HERE, "libhstu_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
 HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
@@ -57,6 +57,7 @@ class HstuAttnBwdParams(C.Structure):
         ("dv_row_stride", C.c_int64), ("dv_head_stride", C.c_int64),
         ("workspace", C.c_void_p), ("total_rows", C.c_int64),
         ("dpos_w", C.c_void_p), ("dts_w", C.c_void_p),
+        ("deterministic", C.c_int),
     ]
 
 

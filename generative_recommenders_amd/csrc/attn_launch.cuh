@@ -142,9 +142,14 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   // workspace layout: [fp32 dq accumulator (several key blocks only)] [bias-gradient partial rows]
   float* acc = nullptr;
   size_t acc_bytes = 0;
+  if (BIAS && bp.deterministic)
+    return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd: deterministic = 1 is not available with the relative bias (the table gradients are "
+                                        "histograms of float atomics)");
+  const size_t slab_bytes = ((size_t)bp.total_rows * p.heads * p.dqk * sizeof(float) + 255) / 256 * 256;
+  const int n_slabs = (nkb > 1 && bp.deterministic) ? nkb : 1;    // deterministic: key block kb stores (not adds) into slab kb
   if (nkb > 1) {
     acc = (float*)bp.workspace;
-    acc_bytes = ((size_t)bp.total_rows * p.heads * p.dqk * sizeof(float) + 255) / 256 * 256;
+    acc_bytes = slab_bytes * n_slabs;
     hipError_t e = hipMemsetAsync(acc, 0, acc_bytes, st);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
   }
@@ -155,14 +160,15 @@ static int launch_bwd_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
     hipError_t e = hipMemsetAsync(partial, 0, (size_t)nblocks * hw * sizeof(float), st);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial, ts_copies, head_loop ? hist : 0);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kBwdThreads), smem, st, bp, nkb, nw, acc, partial, ts_copies, head_loop ? hist : 0,
+                     n_slabs > 1 ? (int64_t)(slab_bytes / sizeof(float)) : (int64_t)0);
   if (int e = check_launch("hstu_attn_bwd")) return e;
   if (nkb > 1) {
     const int64_t n = bp.total_rows * p.heads * (int64_t)(p.dqk / (16 / Elem<T>::kBytes));   // 16 bytes of dq per thread
     int blocks = (int)((n + 255) / 256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(hstu_dq_convert_kernel<T>, dim3(blocks), dim3(256), 0, st, acc, bp.dq, bp.total_rows, p.heads,
-                       p.dqk, bp.dq_row_stride, bp.dq_head_stride);
+                       p.dqk, bp.dq_row_stride, bp.dq_head_stride, n_slabs, (int64_t)(slab_bytes / sizeof(float)));
     if (int e = check_launch("hstu_attn_bwd(dq convert)")) return e;
   }
   if (BIAS) return launch_bias_grad_reduce(partial, nblocks, hw, 2 * p.max_seq_len - 1, bp.dpos_w, bp.dts_w, st);

@@ -203,7 +203,8 @@ size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& bp) {
   if (nw <= 0) return 0;
   const int nkb = (p.max_seq_len + 32 * nw - 1) / (32 * nw);
   size_t bytes = 0;
-  if (nkb > 1) bytes += ((size_t)bp.total_rows * p.heads * p.dqk * sizeof(float) + 255) / 256 * 256;
+  // fp32 dq accumulator: one for the atomic adds of all key blocks, or (deterministic) one slab per key block
+  if (nkb > 1) bytes += (((size_t)bp.total_rows * p.heads * p.dqk * sizeof(float) + 255) / 256 * 256) * (bp.deterministic ? nkb : 1);
   if (p.pos_w) {
     const size_t nblocks = (size_t)((p.batch * p.heads + 7) / 8) * 8 * nkb;
     bytes += (nblocks + 128) * (2 * p.max_seq_len + p.num_buckets) * sizeof(float);   // + the reduce's 128 chunk-sum rows

@@ -96,7 +96,7 @@ HSTU_DEV typename Elem<T>::Frag dsbuf_col_frag(const char* buf, int rowA, int ro
 template <typename T, int DQK, int DV, int NB>
 HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* smem, const char* ds_base,
                             int nw, int kb0, int i0, int db0, int dstep, int64_t off0, int hd, float ds_scale,
-                            float* dq_accum, char* dq_scratch, int lane) {
+                            float* dq_accum, char* dq_scratch, int lane, bool dq_plain = false) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -173,6 +173,11 @@ HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
       for (int i = 0; i < 16; ++i) {
         const int row = 2 * i + hsel;
         float v = *LDS_PTR(const float, dq_scratch + row * 128 + ((((col >> 2) ^ (row & 7)) << 4) | ((col & 3) << 2)));
+        if (dq_plain) {
+          // deterministic: this key block's slab -- every element is written by exactly one wave, once (plain, predicated store)
+          if (col_ok && row <= rmax) base[row * rstride + dc] = v;
+          continue;
+        }
         v = (col_ok && row <= rmax) ? v : 0.f;
         if (!(BIAS_ABLATE & 16) || bp.total_rows == -12345) atomicAdd(base + min(row, rmax) * rstride + dc, v);   // (16: timing experiment, no dq adds)
       }
@@ -184,26 +189,26 @@ HSTU_DEV void bwd_dq_blocks(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 template <typename T, int DQK, int DV>
 HSTU_DEV void bwd_dq_tile(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* smem, const char* ds_base, int nw,
                           int kb0, int i0, int rank, int n_help, int64_t off0, int hd, float ds_scale, float* dq_accum,
-                          char* dq_scratch, int lane) {
+                          char* dq_scratch, int lane, bool dq_plain = false) {
   constexpr int DBQ = DQK / 32;
   if constexpr (DBQ >= 2) {
     if (2 * n_help <= DBQ) {   // few helpers: each takes pairs of blocks (rank, rank + n_help), ...
       for (int db = rank; db + n_help < DBQ; db += 2 * n_help)
-        bwd_dq_blocks<T, DQK, DV, 2>(bp, mc, smem, ds_base, nw, kb0, i0, db, n_help, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
+        bwd_dq_blocks<T, DQK, DV, 2>(bp, mc, smem, ds_base, nw, kb0, i0, db, n_help, off0, hd, ds_scale, dq_accum, dq_scratch, lane, dq_plain);
       if ((DBQ / n_help) & 1)  // odd number of rounds: one single block left per helper
         for (int db = rank + (DBQ / n_help - 1) * n_help; db < DBQ; db += n_help)
-          bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
+          bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane, dq_plain);
       return;
     }
   }
   for (int db = rank; db < DBQ; db += n_help)
-    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
+    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_base, nw, kb0, i0, db, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane, dq_plain);
 }
 
 template <typename T, int DQK, int DV, bool BIAS = false>
 __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAttnBwdParams bp, int nkb, int nw,
                                                                     float* dq_accum, float* bias_partial, int ts_copies,
-                                                                    int bucket_cache_off) {
+                                                                    int bucket_cache_off, int64_t dq_slab_elems) {
   using C = BwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -232,6 +237,11 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   const int len = (int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0);
   const int kb0 = kb * 32 * nw;
   if (kb0 >= len) return;
+  // deterministic mode: key block kb owns slab kb of the workspace and STORES its partial there (hstu_dq_convert_kernel adds
+  // the slabs in block order); otherwise all key blocks add into one accumulator with atomics
+  // (never with the relative bias: the launcher refuses the combination, and the BIAS instantiations sit at the register limit)
+  const bool dq_plain = !BIAS && dq_slab_elems != 0;
+  if (dq_plain) dq_accum += (int64_t)kb * dq_slab_elems;
   const MaskCtx mc = make_mask_ctx(p, b, len);
 #ifdef HSTU_TRACE
   // one key block: the (otherwise unused) workspace pointer carries the trace buffer; several key blocks: the
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
       const char* ds_prev = dsbuf + (((it + 1) & 1) * nw) * C::DSBUF;
       int lane_h = lane;
       asm volatile("" : "+v"(lane_h));
-      bwd_dq_tile<T, DQK, DV>(bp, mc, smem, ds_prev, nw, kb0, i0 + 32, my_rank, n_help, off0, hd, ds_scale, dq_accum, dq_scratch, lane_h);
+      bwd_dq_tile<T, DQK, DV>(bp, mc, smem, ds_prev, nw, kb0, i0 + 32, my_rank, n_help, off0, hd, ds_scale, dq_accum, dq_scratch, lane_h, dq_plain);
     }
     HSTU_MARK(14);
     lds_barrier();  // stage reads done; dS'(it) complete; dS'(it+1) consumed (LDS-only: the dq adds stay in flight)
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
   // ---- dQ of the last visited query tile: every wave is idle now
   if (it_hi > it_lo && wave < C::DBQ) {
     const char* ds_prev = dsbuf + ((it_lo & 1) * nw) * C::DSBUF;
-    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_prev, nw, kb0, it_lo << 5, wave, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane);
+    bwd_dq_blocks<T, DQK, DV, 1>(bp, mc, smem, ds_prev, nw, kb0, it_lo << 5, wave, 1, off0, hd, ds_scale, dq_accum, dq_scratch, lane, dq_plain);
   }
   HSTU_MARK(21);
   // ---- epilogue: dK_w^T / dV_w^T accumulators (column n32 = key) -> rows of dk / dv.  16-bit I/O with the
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(kBwdThreads) void hstu_attn_bwd_kernel(const HstuAt
 // for 16-bit I/O, 4 for fp32 (dqk is a multiple of that -- the boundary checks it -- but not necessarily of 8).
 template <typename T>
 __global__ __launch_bounds__(256) void hstu_dq_convert_kernel(const float* acc, void* dq, int64_t rows, int heads, int dqk,
-                                                              int64_t row_stride, int64_t head_stride) {
+                                                              int64_t row_stride, int64_t head_stride, int n_slabs, int64_t slab_elems) {
   constexpr int VEC = 16 / Elem<T>::kBytes;
   const int pph = dqk / VEC;                // pieces per (row, head)
   const int ppr = heads * pph;              // pieces per row
@@ -660,9 +670,11 @@ __global__ __launch_bounds__(256) void hstu_dq_convert_kernel(const float* acc, 
     const int h = rem / pph, c = (rem - h * pph) * VEC;
     const float* src = acc + i * VEC;       // the accumulator is dense: (row, head, feature)
     T* out = (T*)dq + r * row_stride + h * head_stride + c;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    for (int sl = 1; sl < n_slabs; ++sl) a += *reinterpret_cast<const f32x4*>(src + sl * slab_elems);   // (deterministic: key blocks in order)
     if constexpr (Elem<T>::kBytes == 2) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+      f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+      for (int sl = 1; sl < n_slabs; ++sl) b += *reinterpret_cast<const f32x4*>(src + 4 + sl * slab_elems);
       u32x4 v = {Elem<T>::pk2(a[0], a[1]), Elem<T>::pk2(a[2], a[3]), Elem<T>::pk2(b[0], b[1]), Elem<T>::pk2(b[2], b[3])};
       *reinterpret_cast<u32x4*>(out) = v;
     } else {

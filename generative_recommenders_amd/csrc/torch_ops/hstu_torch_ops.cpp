@@ -171,13 +171,13 @@ std::vector<Tensor> hstu_mha_bwd(int64_t max_seq_len, double alpha, Tensor& dout
     bp.dk_row_stride = gk.stride(0); bp.dk_head_stride = gk.stride(1);
     bp.dv_row_stride = gv.stride(0); bp.dv_head_stride = gv.stride(1);
     bp.total_rows = qp.size(0);
+    // deterministic (flash_api.cpp:291): a sequence that fits ONE key block (max_seq_len <= 224 at 128-wide 16-bit heads) has every
+    // sum in a fixed order anyway.  Longer sequences: each key block's fp32 dq partial goes to a slab of its own and the slabs are
+    // added in block order (ABI v8; the CUDA reference serialises its adds with a semaphore, flash_common.cpp:806-858) -- the
+    // workspace grows by the number of key blocks.
+    bp.deterministic = deterministic ? 1 : 0;
     Tensor ws;
     const size_t ws_bytes = hstu_attn_bwd_workspace_bytes(&bp);
-    // deterministic (flash_api.cpp:291): a sequence that fits ONE key block (max_seq_len <= 224 at 128-wide 16-bit heads) has
-    // every sum in a fixed order -- nothing to do.  Longer sequences add the key blocks' fp32 dq partials with atomics (the
-    // only unordered sum of this op; the workspace is that accumulator): refused rather than silently ignored.
-    TORCH_CHECK(!(deterministic && ws_bytes > 0), "hstu_mha_bwd: deterministic=True is not available for max_seq_len = ", max_seq_len,
-                " at these head dims (several key blocks: dq partials are combined with fp32 atomics); use deterministic=False");
     if (ws_bytes) {
       ws = at::empty({(int64_t)ws_bytes}, qp.options().dtype(at::kByte));
       bp.workspace = ws.data_ptr();

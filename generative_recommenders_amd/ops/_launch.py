@@ -142,9 +142,12 @@ def attn_fwd(q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_a
 def attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale, max_attn_len=0,
              contextual_seq_len=0, min_full_attn_seq_len=0,
              dq: Optional[torch.Tensor] = None, dk: Optional[torch.Tensor] = None,
-             dv: Optional[torch.Tensor] = None, user_order=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+             dv: Optional[torch.Tensor] = None, user_order=None,
+             deterministic: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """dq/dk/dv may be pre-allocated (possibly strided views of one fused buffer), as in
-    hstu::hstu_mha_bwd (flash_api.cpp:111-141)."""
+    hstu::hstu_mha_bwd (flash_api.cpp:111-141).  ``deterministic`` (default: torch's own switch,
+    ``torch.are_deterministic_algorithms_enabled()``): sequences that need several key blocks add their dq partials in block
+    order instead of with atomics (HstuAttnBwdParams::deterministic)."""
     for name, t in (("dout", dout), ("q", q), ("k", k), ("v", v)):
         L.require_gpu_tensor(t, name)
     q, k, v, dout = _aligned_rows(q), _aligned_rows(k), _aligned_rows(v), _aligned_rows(dout)
@@ -163,6 +166,7 @@ def attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha, scale,
     bp.dk_row_stride, bp.dk_head_stride = dk.stride(0), dk.stride(1)
     bp.dv_row_stride, bp.dv_head_stride = dv.stride(0), dv.stride(1)
     bp.total_rows = q.shape[0]
+    bp.deterministic = int(torch.are_deterministic_algorithms_enabled() if deterministic is None else deterministic)
     ws_bytes = L.lib().hstu_attn_bwd_workspace_bytes(C.byref(bp))
     ws = None
     if ws_bytes:

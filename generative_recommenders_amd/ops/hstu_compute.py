@@ -81,20 +81,22 @@ def draw_dropout_seed() -> int:
 _UVQK_LINEAR = os.environ.get("HSTU_UVQK_LINEAR", "1") != "0"
 
 
-_KMAJOR_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_KMAJOR_CACHE: dict = {}      # id(parameter) -> (weak reference, (version, dtype, data_ptr), copy); tensors compare element-wise,
+                               # so they cannot key a (weak) dictionary themselves
 
 
 def _kmajor(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """The (in, out) projection weight as a K-contiguous (out, in) copy in the activations' dtype: ONE transposing, casting
     pass, cached per parameter until the parameter changes (its version counter: an optimizer step, a load_state_dict) --
     forward, the recompute in backward and every inference call of an unchanged weight share one copy."""
-    hit = _KMAJOR_CACHE.get(weight)
+    wid = id(weight)
     key = (weight._version, dtype, weight.data_ptr())
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    hit = _KMAJOR_CACHE.get(wid)
+    if hit is not None and hit[0]() is weight and hit[1] == key:
+        return hit[2]
     wt = torch.empty((weight.shape[1], weight.shape[0]), dtype=dtype, device=weight.device)
     wt.copy_(weight.detach().t())
-    _KMAJOR_CACHE[weight] = (key, wt)
+    _KMAJOR_CACHE[wid] = (weakref.ref(weight, lambda _r, wid=wid: _KMAJOR_CACHE.pop(wid, None)), key, wt)
     return wt
 
 

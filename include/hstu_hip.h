@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 7
+#define HSTU_ABI_VERSION 8
 
 enum {
   HSTU_OK = 0,
@@ -121,6 +121,12 @@ typedef struct HstuAttnBwdParams {
   int64_t total_rows;     /* rows of q/k/v (= seq_offsets[B]), needed to size/zero the workspace */
   float* dpos_w;          /* out (2N-1) fp32, required iff fwd.pos_w != NULL */
   float* dts_w;           /* out (num_buckets+1) fp32, required iff fwd.ts_w != NULL */
+  int deterministic;      /* ABI v8: != 0 -> every sum in a fixed order (hstu::hstu_mha_bwd's `deterministic`, flash_api.cpp:291;
+                           * the CUDA reference serialises its dQ adds with a semaphore, flash_common.cpp:806-858).  One key block
+                           * (the folded / 4-wave / one-wave kernels): always the case.  Several key blocks: each block's fp32 dq
+                           * partial goes to a slab of its own and the slabs are added in block order (workspace grows by the
+                           * number of key blocks: hstu_attn_bwd_workspace_bytes accounts for it).  With the research-path bias
+                           * (table gradients are histograms of float atomics) the call is refused: HSTU_EUNSUPPORTED. */
 } HstuAttnBwdParams;
 
 /* library identity / errors */

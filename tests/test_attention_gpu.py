@@ -387,16 +387,23 @@ def test_torch_library_operator_seam():
     r1 = torch.ops.hstu.hstu_mha_bwd(c["N"], c["alpha"], do, q.detach(), k.detach(), v.detach(), torch.empty_like(q), torch.empty_like(k),
                                      torch.empty_like(v), off, True, nt, None, c["w"], 0, 0, False, True, 0)
     assert torch.equal(r1[0], q2.grad) and torch.equal(r1[1], k2.grad) and torch.equal(r1[2], v2.grad)
-    # ... several key blocks (fp32 atomics into the dq accumulator): refused, not silently ignored
+    # ... several key blocks: the key blocks' fp32 dq partials go to slabs of their own, added in block order (ABI v8): bit-identical
+    # run to run, and equal to the atomic path up to the order of three fp32 additions
     Nl = 600
-    offl = torch.tensor([0, Nl], device=DEV)
-    ql = torch.randn(Nl, 2, 64, device=DEV, dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="deterministic=True is not available"):
-        torch.ops.hstu.hstu_mha_bwd(Nl, 0.1, ql, ql, ql, ql, torch.empty_like(ql), torch.empty_like(ql), torch.empty_like(ql), offl, True,
-                                    None, None, 0, 0, 0, False, True, 0)
-    res_l = torch.ops.hstu.hstu_mha_bwd(Nl, 0.1, ql, ql, ql, ql, torch.empty_like(ql), torch.empty_like(ql), torch.empty_like(ql), offl,
-                                        True, None, None, 0, 0, 0, False, False, 0)
-    assert all(bool(torch.isfinite(t.float()).all()) for t in res_l)
+    offl = torch.tensor([0, Nl, Nl + 417], device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ql, kl, vl, dol = (torch.randn(Nl + 417, 2, 64, device=DEV, dtype=torch.bfloat16, generator=g) * 0.5 for _ in range(4))
+    run = lambda det: torch.ops.hstu.hstu_mha_bwd(Nl, 0.1, dol, ql, kl, vl, torch.empty_like(ql), torch.empty_like(kl), torch.empty_like(vl),  # noqa: E731
+                                                  offl, True, None, None, 0, 0, 0, False, det, 0)
+    d1, d2, nd = run(True), run(True), run(False)
+    assert all(torch.equal(a, b) for a, b in zip(d1, d2))
+    assert all(bool(torch.isfinite(t.float()).all()) for t in d1)
+    assert torch.equal(d1[1], nd[1]) and torch.equal(d1[2], nd[2])          # dk / dv never depended on an unordered sum
+    rel = float((d1[0].float() - nd[0].float()).norm() / nd[0].float().norm())
+    assert rel < 2e-3, rel                                                  # (bf16 outputs: one rounding apart at most)
+    rq, _, _ = O.hstu_mha_bwd(Nl, 0.1, dol.double().cpu().numpy(), ql.double().cpu().numpy(), kl.double().cpu().numpy(),
+                              vl.double().cpu().numpy(), offl.cpu().numpy())
+    assert float(np.linalg.norm(d1[0].double().cpu().numpy() - rq) / np.linalg.norm(rq)) < 3.8e-3
     x = torch.tensor([3, 0, 5], device=DEV)
     assert torch.ops.hstu.complete_cumsum(x).tolist() == [0, 3, 3, 8]
     assert torch.ops.hstu.hstu_mha_fwd(c["N"], c["alpha"], q.detach().to("meta"), k.detach().to("meta"),

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Tools-only comparator: the REFERENCE's own Triton HSTU attention
+(generative_recommenders/ops/triton/triton_hstu_attention.py, staged unmodified by tools/stage_reference_triton.sh into the
+git-ignored _ref_scratch/) on the same MI355X, same inputs as bench.py's M-full / M-jag (q, k, v strided views of one fused
+buffer), forward and backward timed with CUDA events after the autotuner has settled, next to this repo's kernels, and the
+largest absolute difference between the two.  Never imported by the package, the tests or bench.py.
+
+    python tools/ref_triton_compare.py [--users 8192] [--workloads M-full,M-jag] [--iters 20]
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "_ref_scratch"))
+import torch  # noqa: E402
+
+
+def make(workload, B, N, H, d, dev):
+    g = torch.Generator(device=dev).manual_seed(1001)
+    if workload == "M-full":
+        lengths = torch.full((B,), N, dtype=torch.int64, device=dev)
+    else:
+        lengths = torch.randint(int(0.9 * N), N, (B,), generator=g, device=dev, dtype=torch.int64)
+    off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(lengths, 0)
+    L = int(off[-1])
+    fused = torch.empty(L, H, 3 * d, device=dev, dtype=torch.bfloat16).uniform_(-0.01, 0.01, generator=g)
+    do = torch.randn(L, H, d, device=dev, dtype=torch.bfloat16, generator=g)
+    return off, fused, do, L
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=8192)
+    ap.add_argument("--workloads", default="M-full,M-jag")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = "cuda"
+    N, H, d = 200, 4, 128
+    alpha = d ** -0.5
+    print(f"torch {torch.__version__}, device {torch.cuda.get_device_name(0)}")
+    from generative_recommenders_amd.ops.hstu_attention import hstu_mha
+    try:
+        import triton
+        print(f"triton {triton.__version__}")
+        t0 = time.time()
+        # API drift, not a change of the kernel: the reference (June 2025) names Triton's experimental TMA entry points of that
+        # time inside its `ENABLE_TMA` branches.  ENABLE_TMA is False here (NVIDIA-only feature) and the branches are never
+        # traced, but Triton 3.6's return-statement pre-scan resolves every attribute NAME under a runtime `if` -- and the names
+        # are gone.  Stubs that raise if they were ever called let the pre-scan pass; the reference file itself stays as it is.
+        import triton.language as tl
+        import triton.language.extra.cuda as tlcuda
+
+        def _gone(*_a, **_k):
+            raise RuntimeError("experimental TMA entry point called: not available in this Triton")
+
+        shimmed = []
+        for mod, names in ((tl, ("_experimental_descriptor_load", "_experimental_descriptor_store")),
+                           (tlcuda, ("experimental_device_tensormap_create2d", "experimental_tensormap_fenceproxy_acquire"))):
+            for n in names:
+                if not hasattr(mod, n):
+                    setattr(mod, n, _gone)
+                    shimmed.append(f"{mod.__name__}.{n}")
+        print("names absent from this Triton, stubbed for the pre-scan (never called):", shimmed or "none")
+        from generative_recommenders.ops.triton.triton_hstu_attention import triton_hstu_mha
+        print(f"reference Triton module imported in {time.time() - t0:.1f} s")
+    except Exception:  # noqa: BLE001
+        print("IMPORT OF THE REFERENCE TRITON KERNEL FAILED:")
+        traceback.print_exc()
+        triton_hstu_mha = None
+    for wl in a.workloads.split(","):
+        off, fused, do, L = make(wl, a.users, N, H, d, dev)
+        per_tok_f, per_tok_b = H * 4 * d * 2, H * 7 * d * 2
+        print(f"== {wl}: {a.users} users, {L} rows, {H} heads of {d}, bf16; algorithmic bytes fwd {L * per_tok_f / 1e9:.3f} GB, bwd {L * per_tok_b / 1e9:.3f} GB")
+        res = {}
+        for name, fn in (("this repo (HIP)", hstu_mha), ("reference Triton", triton_hstu_mha)):
+            if fn is None:
+                continue
+            try:
+                f = fused.detach().clone().requires_grad_()
+                q, k, v = torch.split(f, [d, d, d], dim=-1)
+                t0 = time.time()
+                out = fn(N, alpha, q, k, v, off)
+                out.backward(do)
+                torch.cuda.synchronize()
+                first = time.time() - t0
+                grad = f.grad.clone()
+                with torch.no_grad():
+                    ms_f = timed(lambda: fn(N, alpha, q, k, v, off), a.iters)
+
+                def fb():
+                    f.grad = None
+                    fn(N, alpha, q, k, v, off).backward(do)
+
+                ms_fb = timed(fb, a.iters)
+                ms_b = ms_fb - ms_f
+                res[name] = (out.detach(), grad)
+                print(f"  {name:18s} first call {first:7.1f} s (compile / autotune) | fwd {ms_f:7.3f} ms ({L * per_tok_f / ms_f / 1e6 / 8000:.3f} of 8 TB/s) | "
+                      f"fwd+bwd {ms_fb:7.3f} ms | bwd (difference) {ms_b:7.3f} ms ({L * per_tok_b / max(ms_b, 1e-9) / 1e6 / 8000:.3f}) | "
+                      f"user-seqs/s {a.users / ms_fb * 1e3:,.0f}")
+            except Exception as e:  # noqa: BLE001
+                print(f"  {name}: FAILED")
+                # the whole chain, innermost cause first (a Triton CompilationError wraps the real error)
+                chain, cur = [], e
+                while cur is not None:
+                    chain.append(cur)
+                    cur = cur.__cause__ or cur.__context__
+                for c in reversed(chain):
+                    txt = "".join(traceback.format_exception_only(type(c), c))
+                    print("    caused by: " + txt.strip()[:3000].replace("\n", "\n      "))
+        if len(res) == 2:
+            (o1, g1), (o2, g2) = res.values()
+            print(f"  max |out diff| {float((o1.float() - o2.float()).abs().max()):.3e} (max |out| {float(o1.float().abs().max()):.3e}); "
+                  f"max |grad diff| {float((g1.float() - g2.float()).abs().max()):.3e} (max |grad| {float(g1.float().abs().max()):.3e})")
+
+
+if __name__ == "__main__":
+    main()
