@@ -23,6 +23,9 @@ static int launch_fwd_inst(const HstuAttnParams& p, hipStream_t st) {
   if constexpr (BIAS && sizeof(T) == 2) {   // (fp32 I/O: the plain kernel; its head-loop variant spills at 128 x 128)
     if (head_loop) kern = hstu_attn_fwd_kernel<T, DQK, DV, true, true>;
   }
+  if constexpr (!BIAS && sizeof(T) == 2 && DQK == DV && (DQK == 64 || DQK == 128)) {
+    if (attn_fwd_precise_enabled()) kern = hstu_attn_fwd_kernel<T, DQK, DV, false, false, true>;
+  }
   const int smem = C::SMEM + tables + (head_loop ? cache : 0);
   if (smem > kLdsBudget) return set_error(HSTU_EUNSUPPORTED, "hstu_attn_fwd: max_seq_len %d needs %d bytes of LDS for the bias tables", p.max_seq_len, smem);
   if (smem > 64 * 1024) {

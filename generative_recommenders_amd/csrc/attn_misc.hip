@@ -136,6 +136,8 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   else if (bwd && attn_bwd_fold_bias_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_bias_kernel<%s,64>", dt);
   else if (!bwd && attn_fwd_head_loop_applicable(p, attn_fwd_ring_bytes(p.dtype == HSTU_DTYPE_F32 ? 4 : 2, a, v), nullptr, nullptr))
     snprintf(buf, len, "hstu_attn_fwd_kernel<%s,%d,%d,bias,heads>", dt, a, v);
+  else if (!bwd && !p.pos_w && p.dtype != HSTU_DTYPE_F32 && a == v && (a == 64 || a == 128) && attn_fwd_precise_enabled())
+    snprintf(buf, len, "hstu_attn_fwd_kernel<%s,%d,%d,precise>", dt, a, v);
   else snprintf(buf, len, "hstu_attn_%s_kernel<%s,%d,%d%s>", bwd ? "bwd" : "fwd", dt, a, v, p.pos_w ? ",bias" : "");
   return HSTU_OK;
 }
@@ -171,6 +173,11 @@ bool attn_bwd_fold_bias_applicable(const HstuAttnBwdParams& bp) {
   const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;
   if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
   return attn_bwd_fold_bias_lds(p, (7 + 2) * 2 * 32 * 64 * 2 + 8 * 32 * 64, nullptr, nullptr, nullptr);
+}
+
+bool attn_fwd_precise_enabled() {
+  static const bool on = [] { const char* e = getenv("HSTU_ATTN_PRECISE"); return e && e[0] == '1'; }();
+  return on;
 }
 
 // HSTU_BIAS_HEAD_LOOP=0: one workgroup per (user, head) for the research-path backward, as before (A/B measurements)

@@ -54,6 +54,9 @@ int attn_bwd_tiles_per_block(int dtype, int dqk, int dv, int max_seq_len, int ex
 // LDS bytes of the research-path bias state of a backward workgroup (histograms with *ts_copies privatised copies of
 // the time-bucket histogram + the staged tables) and the number of copies chosen; 0 without bias
 bool attn_bias_head_loop_enabled();
+// HSTU_ATTN_PRECISE=1: the forward's P' as two 16-bit fragments (value + rounding remainder) for 16-bit I/O at 64 x 64 / 128 x 128
+// without bias: output error at the rounding floor of the I/O dtype, ~20-25 % slower (hstu_attn_fwd.cuh, PRECISE)
+bool attn_fwd_precise_enabled();
 // research-path forward, short sequences: does one workgroup per (user, query block) walk the heads (hstu_attn_fwd.cuh,
 // HEADS instantiation)?  ONE decision for the launcher and for attn_kernel_name.  `ring_bytes` = the K/V ring of the
 // instantiation (FwdCfg::SMEM); *tables / *cache = LDS bytes of the staged tables and of the bucket bytes.

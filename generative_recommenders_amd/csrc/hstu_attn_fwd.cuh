@@ -236,8 +236,12 @@ HSTU_DEV void store4(char* row_ptr, int d0, float x0, float x1, float x2, float 
   }
 }
 
-template <typename T, int DQK, int DV, bool BIAS = false, bool HEADS = false>
-__global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb, int bucket_cache_off) {
+// PRECISE (HSTU_ATTN_PRECISE=1; 16-bit I/O without bias): P' enters the second MFMA as TWO 16-bit fragments, its rounded value
+// and the rounding's remainder -- the kernel's own error (P' rounded to the I/O dtype before O += V^T P'^T, 1.66e-3 relative
+// for bf16: as large as the rounding of the output itself) drops out, at the price of 8 more registers (two waves per SIMD
+// instead of three) and a second PV MFMA per fragment.
+template <typename T, int DQK, int DV, bool BIAS = false, bool HEADS = false, bool PRECISE = false>
+__global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void hstu_attn_fwd_kernel(const HstuAttnParams p, int nqb, int bucket_cache_off) {
   using C = FwdCfg<T, DQK, DV>;
   using E = Elem<T>;
   using Frag = typename E::Frag;
@@ -506,6 +510,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
       HSTU_MID_STEP();      // every wave has read the K tile (its LDS reads retired before the MFMAs issued): that half of the slot is free
       HSTU_MARK(11);
       Frag pb[2];
+      [[maybe_unused]] Frag pbl[2];   // PRECISE: the remainders of P' after its rounding to the I/O dtype
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {   // two halves keep only 8 fp32 temporaries live
         float pv[8];
@@ -587,6 +592,12 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
           }
         }
         pb[h8] = E::pack8(pv);
+        if constexpr (PRECISE) {
+          float lo[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) lo[j] = pv[j] - (float)pb[h8].v[j];
+          pbl[h8] = E::pack8(lo);
+        }
       }
       HSTU_MARK(12);
 #pragma unroll
@@ -595,6 +606,7 @@ __global__ __launch_bounds__(kFwdThreads, HSTU_FWD_MIN_WAVES) void hstu_attn_fwd
         for (int ks = 0; ks < 2; ++ks) {
           Frag a = lds_col_frag<T, C::UPR_V>(Vt, 16 * ks + 4 * hf, 16 * ks + 8 + 4 * hf, 32 * d, lane);
           oacc[d] = E::mma(a, pb[ks], oacc[d]);
+          if constexpr (PRECISE) oacc[d] = E::mma(a, pbl[ks], oacc[d]);
         }
       }
     } else {

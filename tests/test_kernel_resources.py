@@ -85,7 +85,7 @@ def test_no_kernel_spills_or_uses_scratch():
 def test_hot_kernels_stay_under_their_occupancy_limits():
     ks = _kernels()
     find = lambda frag: [v for k, v in ks.items() if frag in k]
-    fwd = find("hstu_attn_fwd_kernelIDF16bLi128ELi128ELb0")          # bf16, 128 x 128, no bias
+    fwd = find("hstu_attn_fwd_kernelIDF16bLi128ELi128ELb0ELb0ELb0E")   # bf16, 128 x 128, no bias, not the precise variant
     fold = find("hstu_attn_bwd_fold_kernelIDF16bLi128ELi128E")
     fold64 = find("hstu_attn_bwd_fold_kernelIDF16bLi64ELi64E")
     assert len(fwd) == 1 and len(fold) == 1 and len(fold64) == 1

@@ -1,0 +1,59 @@
+"""HSTU_ATTN_PRECISE=1 (csrc/hstu_attn_fwd.cuh, PRECISE): the forward feeds P' to the second MFMA as value + rounding remainder, so
+the only rounding left in `out` is the one of the output itself.  Measured here against the fp64 oracle ROUNDED to the I/O dtype
+(north_star's 1e-3 is below what a bf16 output can hold: rounding alone is 1.66e-3 relative Frobenius): the default kernel sits
+at ~1.66e-3 above that floor-reference, the precise one at a fraction of it.  The switch is read once per process: child runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import json, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from generative_recommenders_amd.ops import _launch
+from generative_recommenders_amd.ops.hstu_attention import hstu_mha
+from oracle import hstu_oracle as O
+out = {}
+for dt, d in ((torch.bfloat16, 128), (torch.bfloat16, 64), (torch.float16, 128)):
+    rng = np.random.default_rng(7)
+    N, H = 200, 4
+    lengths = np.array([200, 187, 200, 129, 64, 200]); off = O.complete_cumsum(lengths.astype(np.int64)); L = int(off[-1])
+    mk = lambda: torch.from_numpy(rng.standard_normal((L, H, d)) * 0.5).to(dt)
+    q, k, v = mk(), mk(), mk()
+    got = hstu_mha(N, d ** -0.5, q.cuda(), k.cuda(), v.cuda(), torch.from_numpy(off).cuda()).float().cpu().double().numpy()
+    ref = O.hstu_mha_fwd(N, d ** -0.5, q.double().numpy(), k.double().numpy(), v.double().numpy(), off)
+    ref_r = torch.from_numpy(ref).to(dt).double().numpy()
+    key = f"{str(dt)[6:]}_{d}"
+    out[key] = dict(kernel=_launch.attn_fwd_kernel_name(dt, d, d, N, heads=H),
+                    rel_fro=float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
+                    rel_fro_vs_rounded_ref=float(np.linalg.norm(got - ref_r) / np.linalg.norm(ref)))
+print("RESULT " + json.dumps(out))
+""" % ROOT
+
+
+def _run(precise):
+    env = dict(os.environ, HSTU_ATTN_PRECISE="1" if precise else "0")
+    r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_precise_forward_reaches_the_output_rounding_floor():
+    base, prec = _run(False), _run(True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(dict(default=base, precise=prec), open(os.path.join(ROOT, "gpurun_out", "precise_forward_errors.json"), "w"), indent=1)
+    for key in base:
+        assert "precise" in prec[key]["kernel"] and "precise" not in base[key]["kernel"], (base[key], prec[key])
+        # against the ROUNDED reference: the kernel's own error.  Default: about one output rounding (bf16 1.66e-3); precise: a
+        # fraction of it (what remains: bf16 q, k, v products accumulate in fp32, hardware exp2 / rcp at 1 ulp)
+        floor = 1.66e-3 if key.startswith("bfloat16") else 2.1e-4
+        assert prec[key]["rel_fro_vs_rounded_ref"] <= 0.5 * floor, (key, prec[key])
+        assert prec[key]["rel_fro_vs_rounded_ref"] < 0.5 * base[key]["rel_fro_vs_rounded_ref"], (key, base[key], prec[key])
+        assert prec[key]["rel_fro"] <= 1.1 * floor, (key, prec[key])     # total error = the output's own rounding
