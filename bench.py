@@ -258,6 +258,15 @@ def extra_workloads(args, rank, world, device):
                          "fwd_ms": round(att["fwd_ms"], 4), "bwd_ms": round(att["bwd_ms"], 4), "bound": main["bound"],
                          "frac_fwd": round(fwd["frac"], 4), "frac_bwd": round(main["frac"], 4), "frac_fwd_bwd": round(both["frac"], 4),
                          "kernels": att["kernels"], "what": WORKLOADS[a.workload][4]}
+            # HBM bytes of the committed PMC passes of the same workload / kernels (None: no pass on this instantiation)
+            fname, ent = traffic_entry(a.workload, a.users_per_gpu, a.head_dim, h)
+            tr = {}
+            for side in ("fwd", "bwd"):
+                e = (ent or {}).get(side)
+                if e and e.get("kernel") == att["kernels"].get(side):
+                    tr[side] = {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
+                                "over_algorithmic": round(e["hbm_bytes_per_launch"] / att[side + "_bytes"], 4)}
+            out[name]["traffic"] = dict(tr, file="profiles/" + fname) if tr else None
         except Exception as e:  # the headline number must survive a failure here
             out[name] = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
@@ -506,12 +515,30 @@ def cpu_baseline_layer(args, cores):
                        f"({med * 1e3:.0f} ms each); oracle/dense_torch.py::dense_stu_stack = reference modules/stu.py PyTorch path")
 
 
+TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
+def traffic_entry(workload, users, head_dim, heads):
+    """the committed PMC passes of this (workload, users, head dim, heads) at bf16, or None"""
+    for name in TRAFFIC_FILES:
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        for ent in tr.get("entries", [tr]):
+            src = ent.get("source", {"workload": "M-full", "users_per_gpu": 8192, "head_dim": 128, "heads": 4, "dtype": "bf16"})
+            if (src.get("workload") == workload and src.get("users_per_gpu") == users and src.get("head_dim") == head_dim
+                    and src.get("heads") == heads and src.get("dtype") == "bf16"):
+                return name, ent
+    return None, None
+
+
 def attach_traffic(res, args, att):
     """HBM bytes from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected with tools/prof_pmc.sh;
     counters cannot be read from inside the process) -- attached only when the run's workload, users, head dim and
     dtype are the ones the passes were taken on"""
     res["roofline"]["traffic"] = None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in TRAFFIC_FILES:
         path = os.path.join(ROOT, "profiles", name)
         try:
             tr = json.load(open(path))
