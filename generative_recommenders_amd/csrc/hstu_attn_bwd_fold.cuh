@@ -51,6 +51,15 @@
 #ifndef FOLD_DMA_FAST
 #define FOLD_DMA_FAST 1    // LDS-DMA source addresses as scalar base + 32-bit lane offset (3 instead of ~20 VALU per chunk)
 #endif
+#ifndef FOLD_DQ32
+#define FOLD_DQ32 1        // head dim 128 without an attention window: the dQ GEMM as 32x32x16 chains, wave = (feature block, side)
+#endif
+#ifndef FOLD_DQ32_AHEAD
+#define FOLD_DQ32_AHEAD 2  // key tiles whose fragments are requested ahead of the chain's MFMAs
+#endif
+#ifndef FOLD_L2_TOUCH
+#define FOLD_L2_TOUCH 0    // (measured: no gain, profiles/r04_fold_dq32_l2touch.txt) 1: the NEXT step's Q / dO tiles are pulled into L2 while this step's pairs run; 2: and, in the last step, the
+#endif                     // next problem's first Q / dO tiles and its K / V tiles 0..3
 #ifndef FOLD_PERSIST
 #define FOLD_PERSIST 2     // 0: one workgroup per (user, head); 1: one workgroup per CU walks the problems; 2: and issues the
 #endif                     // next problem's K/V tiles of the slots its own tail does not use
@@ -86,6 +95,27 @@ HSTU_DEV void dma16_asm(const char* g, uint32_t lds_base) {
 // instructions (hstu_attn_fwd.cuh, tile_dma_fast).  `fast` (workgroup-uniform): strides < 16 MiB and the user's rows within
 // 4 GiB of the base; otherwise 64-bit addresses.
 HSTU_DEV void dma16_saddr(uint32_t off, const char* base, uint32_t lds_base) { dma16_saddr_asm(off, base, lds_base); }
+
+// L2 warm-up of one [32][D] 16-bit tile (D = 128: 64 cache lines of 128 bytes): ONE LDS-DMA instruction of 4 bytes per lane,
+// lane l touching line (row l >> 1, half l & 1), its 256 bytes of payload dropped into `dummy` -- LDS nobody reads before it is
+// rewritten (the issuing wave's own dS' slot; the wave waits for its DMA before it publishes there).  The stage tiles of step
+// k + 1 can only be REQUESTED once step k's pairs have stopped reading the stage (LDS is full: no second stage), and under load
+// their HBM latency (3-5 K cycles) then sits on the step's critical path next to the dQ GEMM; touched a pair phase earlier, the
+// request after the barrier is an L2 hit.  (Round 2 tried this with loads into registers and measured +0.8 %: a register
+// destination has to be waited for.)  32 KiB per CU and step: 1 MiB of an XCD's 4 MiB L2.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+HSTU_DEV void dma4_saddr_asm(uint32_t off, const char* base, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <typename T, int D>
+HSTU_DEV void fold_l2_touch(const char* base, int64_t row_stride_bytes, int row0, int len, const char* dummy, int lane) {
+  static_assert(D * Elem<T>::kBytes == 256, "two 128-byte lines per row");
+  const uint32_t row = (uint32_t)min(row0 + (lane >> 1), len - 1);
+  dma4_saddr_asm(__umul24(row, (uint32_t)row_stride_bytes) + (uint32_t)((lane & 1) << 7), base,
+                 __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dummy));
+}
 
 template <typename T, int D>
 HSTU_DEV void fold_tile_dma(char* tile, const char* base, int64_t row_stride_bytes, int row0, int len, int wave, int lane, bool fast = false) {
@@ -308,6 +338,8 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
     }
   }
   // publish dS' as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3) = chunk hf + 2 rq
+  // (the slot's first 256 bytes may be the landing place of this wave's L2-touch DMA, issued at the top of the step: landed first)
+  if (FOLD_L2_TOUCH && !BX::on && DQK == 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
     const u32x4 w = __builtin_bit_cast(u32x4, dsb[rq >> 1].v);
@@ -553,6 +585,105 @@ HSTU_DEV void fold_dq_phase(const HstuAttnBwdParams& bp, const MaskCtx& mc, cons
 #undef HSTU_FOLD_DQ
 }
 
+// ---- round 4: the dQ GEMM of head dim 128 as 32x32x16 chains -------------------------------------------------------------------
+// The 16x16x32 phase above gives every wave (32 features x 16 query rows) of BOTH query tiles: 8 key-tile slots per step on
+// every wave, 6 transposed reads for 2 small MFMAs per slot, one slot of read-ahead -- 2 K cycles per step of pure LDS latency
+// (removing the phase shortens the kernel by 17 %, `FOLD_ABLATE` 32).  Here wave (db = wave & 3, side = wave >> 2) owns the 32
+// features of block db of ONE query tile (side 0: tile a, key tiles 0..a; side 1: tile b, key tiles 0..b): per key tile two
+// 32x32x16 MFMAs (keys 0..15, 16..31) on 8 transposed reads -- half the reads per MAC, the fragments of tile t + 2 requested
+// before the MFMAs of tile t (straight-line code per tile count).  The sides are unequal (a + 1 against b + 1 tiles) but the
+// longer chain, 7 / 6 / 5 / 4 tiles over the four steps of a full-length problem, is shorter than the 8 slots everybody ran.
+// Results differ from the 16x16x32 phase in summation order only.  Needs every tile on or below the diagonal published
+// (no attention window: a pair the window rules out is skipped and leaves its dS' slot stale).
+template <typename T, int D, int N>
+HSTU_DEV f32x16 fold_dq_chain32(const char* __restrict__ kv, const char* __restrict__ ds0, int ds_step, int db, int lane) {
+  using C = BwdCfg<T, D, D>;
+  using E = Elem<T>;
+  using Frag = typename E::Frag;
+  const int hf = lane >> 5, i16 = lane & 15, g1 = (lane >> 4) & 1;
+  const int ra = 8 * hf, rb = 16 + 8 * hf;
+  // B fragments (dS'^T[key][q]): the lane supplies the address of key row r + (i16 >> 2), query chunk 4 g1 + (i16 & 3)
+  const int chunk = 4 * g1 + (i16 & 3), rr = i16 >> 2;
+  const int o00 = fold_ds_off(ra + rr, chunk), o01 = fold_ds_off(ra + 4 + rr, chunk);
+  const int o10 = fold_ds_off(rb + rr, chunk), o11 = fold_ds_off(rb + 4 + rr, chunk);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    const char* Kt = kv + t * C::PAIR;
+    const char* ds = ds0 + t * ds_step;
+    const Frag a0 = lds_col_frag<T, C::UPR_K>(Kt, ra, ra + 4, 32 * db, lane);      // K^T[d][key]
+    const Frag a1 = lds_col_frag<T, C::UPR_K>(Kt, rb, rb + 4, 32 * db, lane);
+    const Frag b0 = tr_frag16<T>(ds, o00, o01);
+    const Frag b1 = tr_frag16<T>(ds, o10, o11);
+    acc = E::mma(a0, b0, acc);
+    acc = E::mma(a1, b1, acc);
+  }
+  // requested order: the 8 transposed reads of tile t + AHEAD in front of the MFMA pair of tile t
+  {
+    constexpr int AH = FOLD_DQ32_AHEAD < N ? FOLD_DQ32_AHEAD : N;
+    __builtin_amdgcn_sched_group_barrier(0x100, 8 * AH, 0);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      if (t + AH < N) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+  }
+  return acc;
+}
+
+template <typename T, int D>
+HSTU_DEV void fold_dq_phase32(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char* __restrict__ kv, const char* __restrict__ dsbuf,
+                              int a, int bq, bool b_on, int wave, int64_t off0, int hd, float ds_scale, int lane HSTU_TRACE_ARG) {
+  using C = BwdCfg<T, D, D>;
+  using F = FoldCfg<T, D, D>;
+  using E = Elem<T>;
+  static_assert(D == 128, "four feature blocks x two sides = eight waves");
+  const int db = wave & 3, side = wave >> 2;
+  if (side == 1 && !b_on) return;
+  const int n = side ? bq + 1 : a + 1;                  // key tiles 0 .. n - 1
+  const int q0 = 32 * (side ? bq : a);
+  const char* ds0 = side ? dsbuf + (kBwdWaves - 1) * F::DSB : dsbuf;     // side A: slot t, side B: slot 7 - t
+  const int ds_step = side ? -F::DSB : F::DSB;
+  HSTU_MARK(19);
+  f32x16 acc;
+  switch (n) {   // wave-uniform
+    case 1: acc = fold_dq_chain32<T, D, 1>(kv, ds0, ds_step, db, lane); break;
+    case 2: acc = fold_dq_chain32<T, D, 2>(kv, ds0, ds_step, db, lane); break;
+    case 3: acc = fold_dq_chain32<T, D, 3>(kv, ds0, ds_step, db, lane); break;
+    case 4: acc = fold_dq_chain32<T, D, 4>(kv, ds0, ds_step, db, lane); break;
+    case 5: acc = fold_dq_chain32<T, D, 5>(kv, ds0, ds_step, db, lane); break;
+    case 6: acc = fold_dq_chain32<T, D, 6>(kv, ds0, ds_step, db, lane); break;
+    default: acc = fold_dq_chain32<T, D, 7>(kv, ds0, ds_step, db, lane); break;
+  }
+  HSTU_MARK(16);
+  // C layout: column n32 = query row, register r = feature (r & 3) + 8 (r >> 2) + 4 hf of the block.  Lanes n32 and n32 + 32 hold
+  // the same row: v_permlane32_swap pairs their 4-feature groups into runs of 8 features -- lanes 0..31 store the features
+  // [0, 8) and [16, 24) of the block, lanes 32..63 [8, 16) and [24, 32): two 16-byte stores per lane
+  const int n32 = lane & 31, hf = lane >> 5;
+  uint32_t g[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    g[j][0] = E::pk2(acc[4 * j] * ds_scale, acc[4 * j + 1] * ds_scale);
+    g[j][1] = E::pk2(acc[4 * j + 2] * ds_scale, acc[4 * j + 3] * ds_scale);
+  }
+#pragma unroll
+  for (int jp = 0; jp < 4; jp += 2)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(g[jp][h], g[jp + 1][h], false, false);
+      g[jp][h] = sw[0];
+      g[jp + 1][h] = sw[1];
+    }
+  const int qrow = q0 + n32;
+  if (qrow < mc.len && (!(FOLD_ABLATE & 1) || bp.total_rows == -12345)) {
+    char* dst = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB + (32 * db + 8 * hf) * C::EB;
+    gstore16(dst, u32x4{g[0][0], g[0][1], g[1][0], g[1][1]});
+    gstore16(dst + 16 * C::EB, u32x4{g[2][0], g[2][1], g[3][0], g[3][1]});
+  }
+}
+
 // One (user, head) problem `uh` of `total`, on the calling workgroup (all of its LDS).
 template <typename T, int DQK, int DV, typename BX = FoldNoBias>
 HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int total, char* smem, int tid, int lane, int wave,
@@ -655,6 +786,15 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // Q/dO tiles of this step (and, first time, K/V) landed; dS' of the last step consumed
     HSTU_MARK(10);
+    if constexpr (FOLD_L2_TOUCH && !BX::on && DQK == 128) {
+      // next step's Q / dO tiles -> L2 (waves 0..3: one tile each); 32-bit offsets as the DMA plan's
+      if (dma_fast && k + 1 < ns && wave < 4) {
+        const int qa = a - 1, qb = bq + 1;
+        const bool second = wave >= 2;
+        if (!second || qb < qa)
+          fold_l2_touch<T, DQK>((wave & 1) ? dobase : qbase, (wave & 1) ? do_rs : q_rs, 32 * (second ? qb : qa), len, dsbuf + wave * F::DSB, lane);
+      }
+    }
     if (k > 0 && wave == a + 1) {
       // owner of the previous step's diagonal tile: its K tile is dead now (every dQ GEMM of that step is done):
       // park dK in its place; dV was parked before the barrier, so the accumulators are free for a side-B tile
@@ -695,7 +835,16 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
     // ---- phase 2: dQ of the two query tiles, 16 feature columns per wave
     int lane2 = lane;
     asm volatile("" : "+v"(lane2));
-    if (!(FOLD_ABLATE & 32)) fold_dq_phase<T, DQK, DV>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
+    if (!(FOLD_ABLATE & 32)) {
+      bool done32 = false;
+      if constexpr (FOLD_DQ32 && DQK == 128 && DV == 128 && !BX::on) {
+        if (mc.win == 0) {
+          fold_dq_phase32<T, DQK>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
+          done32 = true;
+        }
+      }
+      if (!done32) fold_dq_phase<T, DQK, DV>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
+    }
     HSTU_MARK(17);
     if (kt == wave && wave == a) {
       // diagonal step of side A: no later query tile reaches key tile `wave`, its dK/dV are final (a >= nt/2 in
