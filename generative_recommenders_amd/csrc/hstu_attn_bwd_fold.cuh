@@ -57,6 +57,9 @@
 #ifndef FOLD_DQ32_AHEAD
 #define FOLD_DQ32_AHEAD 2  // key tiles whose fragments are requested ahead of the chain's MFMAs
 #endif
+#ifndef FOLD_COPY_SPLIT
+#define FOLD_COPY_SPLIT 0  // (measured +3.5 % SLOWER: profiles/r04_fold_copy_split.txt) with FOLD_DQ32: the parked tile of the previous step is copied out by the four side-B waves AFTER their (short)
+#endif                     // dQ chain, beside the side-A waves' long chains, instead of by all eight waves in front of the dQ GEMM
 #ifndef FOLD_L2_TOUCH
 #define FOLD_L2_TOUCH 0    // (measured: no gain, profiles/r04_fold_dq32_l2touch.txt) 1: the NEXT step's Q / dO tiles are pulled into L2 while this step's pairs run; 2: and, in the last step, the
 #endif                     // next problem's first Q / dO tiles and its K / V tiles 0..3
@@ -406,10 +409,10 @@ HSTU_DEV void fold_park_tile(const f32x16 (&acc)[D / 32], float scale, char* __r
       *LDS_PTR(u32x2, tile + tile_off<UPR>(n32, 4 * d + rq) + 8 * half) = v;
     }
 }
-template <typename T, int D>
+template <typename T, int D, int NT = kBwdThreads>
 HSTU_DEV void fold_copy_out(const char* __restrict__ tile, char* gtile, int64_t row_stride_bytes, int rows_valid, int tid) {
   constexpr int UPR = D * Elem<T>::kBytes / 16;
-  for (int u = tid; u < 32 * UPR; u += kBwdThreads) {
+  for (int u = tid; u < 32 * UPR; u += NT) {
     const int row = u / UPR, unit = u % UPR;
     u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, unit));
     if (FOLD_PARK_SWAP && UPR >= 16 && ((row >> 1) & 1)) v = u32x4{v[2], v[3], v[0], v[1]};     // (see fold_park_tile)
@@ -826,11 +829,17 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
     __syncthreads();   // dS' of this step published; stage reads done
     HSTU_MARK(15);
     if (k + 1 < ns && !(FOLD_ABLATE & 4)) stage_dma(a - 1, bq + 1, bq + 1 < a - 1);
-    if (k > 0) {   // dk / dv of the previous step's diagonal key tile (parked in K/V slot a + 1): out, by all waves
+    // dk / dv of the previous step's diagonal key tile (parked in K/V slot a + 1): out -- by all waves right here, or (the
+    // 32x32x16 dQ phase, whose side-B waves have the short chains) by waves 4..7 behind their chain
+    constexpr bool kSplitOk = FOLD_COPY_SPLIT && FOLD_DQ32 && DQK == 128 && DV == 128 && !BX::on;
+    const bool copy_split = kSplitOk && mc.win == 0;
+    auto copy_out_prev = [&](auto nt_tag, int t0) {
+      constexpr int NTH = decltype(nt_tag)::value;
       const int kt1 = a + 1;
-      fold_copy_out<T, DQK>(smem + kt1 * C::PAIR, dk_head + (int64_t)(32 * kt1) * dk_rs, dk_rs, len - 32 * kt1, tid);
-      fold_copy_out<T, DV>(smem + kt1 * C::PAIR + C::KT, dv_head + (int64_t)(32 * kt1) * dv_rs, dv_rs, len - 32 * kt1, tid);
-    }
+      fold_copy_out<T, DQK, NTH>(smem + kt1 * C::PAIR, dk_head + (int64_t)(32 * kt1) * dk_rs, dk_rs, len - 32 * kt1, t0);
+      fold_copy_out<T, DV, NTH>(smem + kt1 * C::PAIR + C::KT, dv_head + (int64_t)(32 * kt1) * dv_rs, dv_rs, len - 32 * kt1, t0);
+    };
+    if (k > 0 && !copy_split) copy_out_prev(std::integral_constant<int, kBwdThreads>{}, tid);
     HSTU_MARK(18);
     // ---- phase 2: dQ of the two query tiles, 16 feature columns per wave
     int lane2 = lane;
@@ -844,6 +853,11 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
         }
       }
       if (!done32) fold_dq_phase<T, DQK, DV>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
+    }
+    if (k > 0 && copy_split && wave >= kBwdWaves / 2) {
+      int tid2 = tid;
+      asm volatile("" : "+v"(tid2));
+      copy_out_prev(std::integral_constant<int, kBwdThreads / 2>{}, tid2 - kBwdThreads / 2);
     }
     HSTU_MARK(17);
     if (kt == wave && wave == a) {
