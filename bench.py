@@ -400,7 +400,7 @@ def projection_section(rows, D, device):
     """MFMA utilisation of the six projection GEMMs of one STU layer at the layer section's shape (hipBLASLt through
     torch, bf16; the calls ops/hstu_compute.py makes: linear on a K-contiguous weight copy / addmm with the residual, mm for the data gradients, ops/mm.py's slab-split
     batched GEMM for the weight gradients): TFLOP/s and the fraction of the dense bf16 peak, HIP events around 10 calls each."""
-    from generative_recommenders_amd.ops.hstu_compute import _uvqk_gemm
+    from generative_recommenders_amd.ops.hstu_compute import _uvqk_dgrad, _uvqk_gemm, _uvqk_prepare
     from generative_recommenders_amd.ops.mm import weight_grad_mm
 
     dt = torch.bfloat16
@@ -411,9 +411,10 @@ def projection_section(rows, D, device):
     y3 = torch.randn(rows, 3 * D, device=device, dtype=dt)
     w_out = torch.randn(3 * D, D, device=device, dtype=dt)
     g_out = torch.randn(rows, D, device=device, dtype=dt)
+    w_mul, kmajor = _uvqk_prepare(w_uvqk, dt)      # the K-major copy the product caches per parameter version
     cases = {
-        "uvqk_fwd": (lambda: _uvqk_gemm(x, w_uvqk, b_uvqk), 2.0 * rows * D * 4 * D),      # (incl. the product's transposed weight copy)
-        "uvqk_dgrad": (lambda: torch.mm(g_uvqk, w_uvqk.t()), 2.0 * rows * D * 4 * D),
+        "uvqk_fwd": (lambda: _uvqk_gemm(x, w_mul, kmajor, b_uvqk), 2.0 * rows * D * 4 * D),
+        "uvqk_dgrad": (lambda: _uvqk_dgrad(g_uvqk, w_mul, kmajor), 2.0 * rows * D * 4 * D),
         "uvqk_wgrad": (lambda: weight_grad_mm(x, g_uvqk), 2.0 * rows * D * 4 * D),
         "out_fwd": (lambda: torch.addmm(x, y3, w_out), 2.0 * rows * 3 * D * D),      # + the residual
         "out_dgrad": (lambda: torch.mm(g_out, w_out.t()), 2.0 * rows * 3 * D * D),

@@ -83,3 +83,19 @@ def test_the_headline_backward_is_the_folded_kernel():
     assert _launch.attn_bwd_kernel_name(torch.bfloat16, 64, 64, 200).startswith("hstu_attn_bwd_quad_kernel")
     assert _launch.attn_bwd_kernel_name(torch.float32, 128, 128, 200).startswith("hstu_attn_bwd_kernel")
     assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 256).startswith("hstu_attn_bwd_kernel")
+
+
+def test_bench_projection_section_calls_the_products_gemms():
+    """bench.py's layer leg swallows errors so the headline number survives; this keeps its projection table honest: the
+    section runs against the product's current GEMM helpers and reports all six projections."""
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.modules["bench_under_test"] = bench
+    spec.loader.exec_module(bench)
+    res = bench.projection_section(1024, 256, torch.device(DEV))
+    assert set(res) == {"uvqk_fwd", "uvqk_dgrad", "uvqk_wgrad", "out_fwd", "out_dgrad", "out_wgrad"}
+    assert all(v["tflops"] > 0 for v in res.values())
