@@ -373,6 +373,33 @@ def layer_norm_fwd(x, weight, bias, eps):
     return y, mean, rstd
 
 
+def ln_linear_supported(x, n):
+    """whether the fused LayerNorm + projection kernel takes (rows, k) activations and n output columns"""
+    return bool(x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and
+                L.lib().hstu_ln_linear_fwd_supported(x.shape[0], x.shape[1], n, L.torch_dtype_code(x.dtype)))
+
+
+def ln_linear_fwd(x, ln_weight, ln_bias, eps, w_nk, bias, want_normed=False):
+    """y = LayerNorm(x) @ w_nk.T + bias in one kernel (csrc/hstu_ln_linear.cuh): returns (y, normed_x or None, mean, rstd).
+    ``w_nk``: the (n, k) K-contiguous weight in x's dtype."""
+    L.require_gpu_tensor(x, "x")
+    x = x.contiguous()
+    rows, k = x.shape
+    n = w_nk.shape[0]
+    torch._assert(w_nk.shape[1] == k and w_nk.is_contiguous() and w_nk.dtype == x.dtype, "w_nk must be a contiguous (n, k) tensor of x's dtype")
+    y = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+    normed = torch.empty_like(x) if want_normed else None
+    mean, rstd = _f32(rows, x.device), _f32(rows, x.device)
+    w, b = ln_weight.to(x.dtype).contiguous(), ln_bias.to(x.dtype).contiguous()
+    pb = None if bias is None else bias.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_ln_linear_fwd(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), float(eps), w_nk.data_ptr(),
+                                           None if pb is None else pb.data_ptr(), y.data_ptr(), n,
+                                           None if normed is None else normed.data_ptr(), k, mean.data_ptr(), rstd.data_ptr(),
+                                           rows, k, n, L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
+    return y, normed, mean, rstd
+
+
 def layer_norm_bwd(dy, x, weight, mean, rstd, dresidual=None):
     """``dresidual``: a gradient that reaches x around the norm; added inside the kernel (dx = LN'(dy) + dresidual)."""
     dy, x = dy.contiguous(), x.contiguous()

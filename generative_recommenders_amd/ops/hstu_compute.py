@@ -111,6 +111,21 @@ def _uvqk_gemm(normed_x: torch.Tensor, w: torch.Tensor, kmajor: bool, bias: torc
     return torch.nn.functional.linear(normed_x, w, bias) if kmajor else torch.addmm(bias, normed_x, w)
 
 
+# LayerNorm + the UVQK GEMM as ONE hand-written kernel (csrc/hstu_ln_linear.cuh: x read once, normalised in registers, the
+# weight streamed through LDS) where its shape conditions hold (16-bit activations, embedding dim 512, K-major weight):
+# 442 us against 82 + 577 us for hstu_layer_norm_fwd + hipBLASLt at 204,800 rows x 2048 columns
+# (profiles/r04_ln_linear_bench.txt).  HSTU_LN_LINEAR=0 keeps the two calls.
+_LN_LINEAR = os.environ.get("HSTU_LN_LINEAR", "1") != "0"
+
+
+def _ln_uvqk(x, norm_weight, norm_bias, eps, w, kmajor, bias, want_normed):
+    """(uvqk, normed_x or None, mean, rstd): the fused kernel when it takes the shape, else layer norm + GEMM"""
+    if _LN_LINEAR and kmajor and _launch.ln_linear_supported(x, w.shape[0]):
+        return _launch.ln_linear_fwd(x, norm_weight, norm_bias, eps, w, bias, want_normed=want_normed)
+    normed_x, mean, rstd = _launch.layer_norm_fwd(x, norm_weight, norm_bias, eps)
+    return _uvqk_gemm(normed_x, w, kmajor, bias), normed_x, mean, rstd
+
+
 def _uvqk_dgrad(duvqk: torch.Tensor, w: torch.Tensor, kmajor: bool) -> torch.Tensor:
     return torch.mm(duvqk, w) if kmajor else torch.mm(duvqk, w.t())
 
@@ -222,8 +237,8 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
         norm_weight, norm_bias, uvqk_bias = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_bias))
         uvqk_weight, ctx.kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
-        normed_x, mean, rstd = _launch.layer_norm_fwd(x, norm_weight, norm_bias, norm_eps)
-        uvqk = _uvqk_gemm(normed_x, uvqk_weight, ctx.kmajor, uvqk_bias)
+        uvqk, normed_x, mean, rstd = _ln_uvqk(x, norm_weight, norm_bias, norm_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
+                                              want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
         u_pre = uvqk[:, :hv]
         v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
@@ -257,6 +272,8 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         normed_x = rest.pop(0) if ctx.keep_normed else None
         uvqk = rest.pop(0) if ctx.keep_uvqk else None
         eps, H, A, Hd, N, alpha, w, c = ctx.meta
+        if normed_x is None and uvqk is None:
+            uvqk, normed_x, _, _ = _ln_uvqk(x, nw, nb, eps, W, ctx.kmajor, beta, want_normed=True)
         if normed_x is None:
             normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, eps)
         if uvqk is None:
@@ -304,8 +321,8 @@ class _STULayerFunction(torch.autograd.Function):
         in_nw, in_nb, uvqk_bias, out_nw, out_nb, output_weight = (
             _cast(t, x.dtype) for t in (in_nw, in_nb, uvqk_bias, out_nw, out_nb, output_weight))
         uvqk_weight, ctx.kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
-        normed_x, mean, rstd = _launch.layer_norm_fwd(x, in_nw, in_nb, in_eps)
-        uvqk = _uvqk_gemm(normed_x, uvqk_weight, ctx.kmajor, uvqk_bias)
+        uvqk, normed_x, mean, rstd = _ln_uvqk(x, in_nw, in_nb, in_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
+                                              want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
         v = uvqk[:, hv : 2 * hv].view(-1, num_heads, hidden_dim)
         q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, num_heads, attn_dim)
@@ -340,6 +357,8 @@ class _STULayerFunction(torch.autograd.Function):
         uvqk = rest.pop(0) if ctx.keep[1] else None
         y = rest.pop(0) if ctx.keep[2] else None
         in_eps, out_eps, H, A, Hd, N, alpha, w, c, cat, gn, p_drop, seed = ctx.meta
+        if normed_x is None and uvqk is None:
+            uvqk, normed_x, _, _ = _ln_uvqk(x, nw, nb, in_eps, W, ctx.kmajor, beta, want_normed=True)
         if normed_x is None:
             normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, in_eps)
         if uvqk is None:

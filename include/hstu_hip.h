@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 8
+#define HSTU_ABI_VERSION 9
 
 enum {
   HSTU_OK = 0,
@@ -220,6 +220,17 @@ int hstu_concat_1d_jagged_jagged(const void* values_left, const void* offsets_le
 int hstu_layer_norm_fwd(const void* x, const void* weight, const void* bias, void* y,
                         float* mean, float* rstd, int64_t rows, int32_t dim, float eps,
                         int dtype, void* stream);
+/* ABI v9: y = LayerNorm(x) . W^T + bias as ONE kernel -- the UVQK projection of hstu_compute_uqvk
+ * (ops/hstu_compute.py:62-89: layer_norm + addmm; Triton: ops/triton/triton_layer_norm.py:77-309 followed by
+ * ops/triton/triton_addmm.py:185-340).  x (rows, k) with leading dimension ldx, w_nk the (n, k) K-contiguous weight
+ * (= the reference's (k, n) parameter transposed), y (rows, n) with leading dimension ldy; normed (rows, k; the
+ * normalised rows, as hstu_layer_norm_fwd would write them), mean and rstd (fp32, per row) are optional outputs.
+ * bf16 / fp16, k == 512, n a multiple of 32 up to 4096, 16-byte aligned pointers, leading dimensions multiples of 8:
+ * hstu_ln_linear_fwd_supported says whether a shape qualifies (callers otherwise run hstu_layer_norm_fwd + a GEMM). */
+int hstu_ln_linear_fwd_supported(int64_t rows, int32_t k, int32_t n, int dtype);
+int hstu_ln_linear_fwd(const void* x, int64_t ldx, const void* ln_weight, const void* ln_bias, float eps,
+                       const void* w_nk, const void* bias, void* y, int64_t ldy, void* normed, int64_t ldn,
+                       float* mean, float* rstd, int64_t rows, int32_t k, int32_t n, int dtype, void* stream);
 int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight,
                         const float* mean, const float* rstd, void* dx,
                         float* dweight, float* dbias, float* partial_ws,

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("hstu_attn_bwd_wide_kernel", "hstu_attn_bwd_fold_bias_kernel", "hstu_attn_bwd_fold_kernel", "hstu_attn_bwd_quad_kernel", "hstu_attn_bwd_solo_kernel",
+    for key in ("hstu_ln_linear_fwd_kernel", "Cijk_", "hstu_attn_bwd_wide_kernel", "hstu_attn_bwd_fold_bias_kernel", "hstu_attn_bwd_fold_kernel", "hstu_attn_bwd_quad_kernel", "hstu_attn_bwd_solo_kernel",
                 "hstu_attn_fwd_solo_kernel", "hstu_attn_bwd_kernel", "hstu_attn_fwd_kernel", "hstu_dq_convert", "layer_norm", "norm_mul", "silu"):
         if key in name:
             return key
@@ -26,13 +26,13 @@ def main(root):
         # steady state: the timed launches of bench.py are the LAST `steps` dispatches of each attention kernel (the
         # first ones are its warm-up, at ramping clocks); bench.py's HIP-event figure is over exactly those
         print("\n| kernel | dispatches | avg us, all | avg us, warm-up excluded | median us |\n|---|---|---|---|---|")
-        for (name,) in list(cur.execute("select distinct name from kernels where name like '%hstu_attn%'")):
+        for (name,) in list(cur.execute("select distinct name from kernels where name like '%hstu_attn%' or name like '%hstu_ln_linear%' or name like 'Cijk_%'")):
             d = [r[0] / 1e3 for r in cur.execute("select duration from kernels where name = ? order by start", (name,))]
             warm = int(os.environ.get("PROF_WARMUP", "2"))
             tail = d[warm:] if len(d) > warm else d
             sd = sorted(tail)
             print(f"| {name[:70]} | {len(d)} | {sum(d) / len(d):.1f} | {sum(tail) / len(tail):.1f} | {sd[len(sd) // 2]:.1f} |")
-        rows = list(cur.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels where name like '%hstu_attn%' group by name"))
+        rows = list(cur.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels where name like '%hstu_attn%' or name like '%hstu_ln_linear%' or name like 'Cijk_%' group by name"))
         print("\n| kernel | arch VGPR | accum VGPR | SGPR | LDS bytes | grid | block |\n|---|---|---|---|---|---|---|")
         for r in rows:
             print("| " + " | ".join(str(x)[:60] for x in r) + " |")
