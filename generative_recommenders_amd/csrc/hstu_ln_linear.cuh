@@ -26,6 +26,8 @@
 // accumulation; half a VALU instruction per element and statistic); when that form of the variance would cancel
 // (E[x^2] > 64 var in any row of the wave) the wave recomputes the centred sum of squares the long way.
 #pragma once
+#include <type_traits>
+
 #include "hstu_common.cuh"
 #include "capi_internal.h"
 
@@ -40,8 +42,20 @@ namespace hstu {
 #ifndef LNL_DRAIN_STORES
 #define LNL_DRAIN_STORES 0 // 1: every step waits for the previous step's stores of y as well (vmcnt(0))
 #endif
+#ifndef LNL_PRELOAD
+#define LNL_PRELOAD 0      // request the next block's rows of x under the last tile of a block (measured: 482 against 448 us -- the
+                           // 32 fragment-shaped loads per lane hold up the wave's other memory instructions and the MFMAs behind them)
+#endif
+#ifndef LNL_NT_STORES
+#define LNL_NT_STORES 1    // y leaves with the non-temporal hint (443 -> 421 us)
+#endif
+#ifndef LNL_X_LINES
+#define LNL_X_LINES 1      // rows of x are requested as whole 128-byte lines (8 lanes per row) and turned into MFMA fragments through
+#endif                     // the wave's LDS staging; 0: fragment-shaped loads (32 rows x 32 bytes per instruction)
 #ifndef LNL_ABLATE
-#define LNL_ABLATE 0       // experiments: 1 no stores of y, 2 no MFMA, 4 no W DMA after the prefill, 8 skip the LN arithmetic
+#define LNL_ABLATE 0       // experiments: 1 no stores of y, 2 no MFMA, 4 no W DMA after the prefill, 8 skip the LN arithmetic,
+                           // 16 no packing of finished tiles, 32 no bias reads, 64 no loads of x, 128 no barrier / vmcnt wait,
+                           // 256 every W request twice, 512 all stores of y land in the first MiB (cache-resident)
 #endif
 
 constexpr int kLnlK = 512;
@@ -52,6 +66,7 @@ constexpr int kLnlKS = kLnlK / 16;                   // MFMAs per 32 x 32 output
 constexpr int kLnlTileBytes = 32 * kLnlK * 2;        // 32 KiB
 constexpr int kLnlRingBytes = LNL_STAGES * kLnlTileBytes;
 constexpr int kLnlMaxN = 4096;
+constexpr int kLnlStageBytes = 4096;              // per wave: 32 rows x 128 bytes of x on their way in, 32 x 64 of y on their way out
 
 struct LnLinearArgs {
   const void* x; const void* ln_w; const void* ln_b; const void* w; const void* bias;
@@ -77,14 +92,26 @@ struct LnLinearArgs {
 #define LNL_MARK(tag)
 #endif
 
-static inline int lnl_smem_bytes(int n) { return kLnlRingBytes + 2 * kLnlK * 4 + n * 4 + kLnlWaves * 2048; }   // ring, LN tables, bias, the waves' store staging
+static inline int lnl_smem_bytes(int n) { return kLnlRingBytes + 2 * kLnlK * 4 + n * 4 + kLnlWaves * kLnlStageBytes; }   // ring, LN tables, bias, the waves' staging
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 HSTU_DEV void lnl_dma16(uint32_t off, const char* base, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_base) : "memory", "m0");
+  // wave-uniform by construction; said explicitly, or a control-flow join can leave them in vector registers
+  const uint64_t b = (uint64_t)(uintptr_t)base;
+  base = (const char*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                                   (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b));   // (the builtin returns int)
+  lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+  // s_nop 4: a v_readfirstlane result needs 5 wait states before a memory instruction may take it as its address, and the
+  // hazard pass does not look inside an asm statement
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_base) : "memory", "m0");
 }
 #pragma clang diagnostic pop
+
+HSTU_DEV void lnl_gstore(void* p, u32x4 v) {
+  if (LNL_NT_STORES) gstore16_nt(p, v);
+  else gstore16(p, v);
+}
 
 template <typename T> struct LnlDot;
 template <> struct LnlDot<bf16_t> {
@@ -108,17 +135,57 @@ template <> struct LnlDot<f16_t> {
 
 // The 32 rows of the calling wave, normalised, as MFMA operand fragments: xf[ks] = elements [16 ks + 8 h, +8) of row
 // `lane & 31` (h = lane >> 5).
+// where lane (m, h) finds its pieces of row m of block `blk` (rows past the end: the last row, never stored)
+HSTU_DEV const char* lnl_row_ptr(const LnLinearArgs& g, int64_t blk, int wave, int lane) {
+  const int64_t row = blk * kLnlBlockRows + wave * 32 + (lane & 31);
+  return (const char*)g.x + ((row < g.rows ? row : g.rows - 1) * g.ldx + 8 * (lane >> 5)) * 2;
+}
+
 template <typename T>
 HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam, const float* bet, int wave, int lane,
-                            u32x4 (&xf)[kLnlKS]) {
+                            u32x4 (&xf)[kLnlKS], bool preloaded, char* stage) {
   using DT = LnlDot<T>;
   const int m = lane & 31, h = lane >> 5;
   const int64_t row = blk * kLnlBlockRows + wave * 32 + m;
   const bool ok = row < g.rows;
-  const int64_t lrow = ok ? row : g.rows - 1;
-  const char* xp = (const char*)g.x + (lrow * g.ldx + 8 * h) * 2;
+  const char* xp = lnl_row_ptr(g, blk, wave, lane);
+  if (preloaded && !LNL_X_LINES) {
+    // the raw rows are already on their way: requested fragment by fragment under the last tile of the block before
+  } else if (LNL_ABLATE & 64) {
 #pragma unroll
-  for (int ks = 0; ks < kLnlKS; ++ks) xf[ks] = gload16(xp + ks * 32);
+    for (int ks = 0; ks < kLnlKS; ++ks) asm volatile("" : "=v"(xf[ks]));
+  } else if (LNL_X_LINES) {
+    // instruction 4 c + q fetches bytes [128 c, 128 c + 128) of the rows 8 q .. 8 q + 7 of the wave: lane L = (row 8 q + (L >> 3),
+    // piece L & 7) -- eight whole lines per instruction instead of 32 quarter lines.  Each 128-byte column chunk (4 MFMA steps)
+    // then crosses the wave's staging: piece p of row r sits at slot p ^ ((r >> 1) & 7) of the row (conflict-free for the
+    // 8-lane groups of the stores and the 16-lane groups of the loads); lane (m, h) picks up pieces 2 j + h of row m.
+    const int pr = lane >> 3, pp = lane & 7;
+    const char* rp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t r = blk * kLnlBlockRows + wave * 32 + 8 * q + pr;
+      rp[q] = (const char*)g.x + (r < g.rows ? r : g.rows - 1) * g.ldx * 2 + 16 * pp;
+    }
+    if (!preloaded) {      // (else: requested under the last tile of the block before, the same way)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xf[4 * c + q] = gload16(rp[q] + 128 * c);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 8 * q + pr;
+        *LDS_PTR(u32x4, stage + r * 128 + ((pp ^ ((r >> 1) & 7)) << 4)) = xf[4 * c + q];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[4 * c + j] = *LDS_PTR(const u32x4, stage + m * 128 + (((2 * j + h) ^ ((m >> 1) & 7)) << 4));
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < kLnlKS; ++ks) xf[ks] = gload16(xp + ks * 32);
+  }
   if (LNL_ABLATE & 8) return;
   float s = 0.f, q = 0.f;
 #pragma unroll
@@ -268,7 +335,7 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
 #endif
   LNL_MARK(1);
   int cslot = 0;
-  char* stage = (char*)(bia + g.n) + wave * 2048;
+  char* stage = (char*)(bia + g.n) + wave * kLnlStageBytes;
   // fragment ks of a ring tile = 16-byte unit 2 ks + h of row m, at slot (2 ks + h) ^ swz(m) of the row: the swizzle touches
   // the low four bits of the unit only, so 8 addresses (ks & 7) + an immediate 256 (ks >> 3) cover the 32 fragments
   uint32_t fa[8];
@@ -302,7 +369,10 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
   char* pk_dst = nullptr;
   bool ok_lo = false, ok_hi = false;     // this lane's two rows of the block exist
   int n_stores = 0;                      // store instructions of a tile that the wave really issues (none for a half without rows)
-  auto step = [&](f32x16& cur, f32x16& oth, bool have_prev, bool have_packed, char* row_dst) {
+  // (PRE: the variant for the last tile of a block that requests the next block's rows; a template parameter, not a flag --
+  // 32 conditional loads would cut every chain into basic blocks)
+  auto step = [&](f32x16& cur, f32x16& oth, bool have_prev, bool have_packed, char* row_dst, const char* xnext, auto pre) {
+    constexpr bool PRE = decltype(pre)::value;
     const int nslot = next_slot(cslot);
     const bool do_issue = issued < nsteps && !((LNL_ABLATE & 4) && issued >= LNL_STAGES);
     const char* wbase = (const char*)g.w + (int64_t)it * kLnlTileBytes;
@@ -314,28 +384,38 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
       xb.v = __builtin_bit_cast(typename E::vec8, xf[ks]);
       if (!(LNL_ABLATE & 2)) cur = E::mma(wf[ks % LNL_AHEAD], xb, cur);
       else cur[ks & 15] += (float)wf[ks % LNL_AHEAD].v[0] + (float)xb.v[0];
-      if (ks == 3 && have_packed && ok_lo) gstore16(pk_dst, pk.lo);
-      if (ks == 9 && have_packed && ok_hi) gstore16(pk_dst + 16 * g.ldy * 2, pk.hi);
+      if (ks == 3 && have_packed && ok_lo) lnl_gstore(pk_dst, pk.lo);
+      if (ks == 9 && have_packed && ok_hi) lnl_gstore(pk_dst + 16 * g.ldy * 2, pk.hi);
       if (ks == kLnlKS / 2 - 1) {
         LNL_MARK(11);
         // no lgkmcnt wait: the reads in flight are of THIS tile; the slot requested below was read by MFMAs that have issued.
         // vmcnt counts in issue order: behind the next tile's four requests there are only this step's two stores
-        const int behind = have_packed && !LNL_DRAIN_STORES ? n_stores : 0;
-        if (behind == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        // ... and, in the last tile of a block, the 15 fragments of the next block's rows requested so far
+        const int behind = (have_packed && !LNL_DRAIN_STORES ? n_stores : 0) + (PRE ? kLnlKS / 2 - 1 : 0);
+        if (LNL_ABLATE & 128) {
+        } else if (behind == 17) asm volatile("s_waitcnt vmcnt(17)\n\ts_barrier" ::: "memory");
+        else if (behind == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        else if (behind == 15) asm volatile("s_waitcnt vmcnt(15)\n\ts_barrier" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
         else if (behind == 1) asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         LNL_MARK(12);
       }
+      // fragment ks of this block's rows has had its last MFMA: its registers take the next block's row pieces now, and the
+      // load latency passes under the rest of the chain instead of in front of the next block
+      if constexpr (PRE) xf[ks] = LNL_X_LINES ? gload16(xnext + (ks & 3) * (8 * g.ldx * 2) + 128 * (ks >> 2)) : gload16(xnext + ks * 32);
       if (ks >= kLnlKS / 2 && ks % 4 == 0 && do_issue) {
         const int j = (ks - kLnlKS / 2) / 4;
         lnl_dma16(uo[j], wbase, dst0 + j * 1024);
+        if (LNL_ABLATE & 256) lnl_dma16(uo[j], wbase, dst0 + j * 1024);
       }
       wf[ks % LNL_AHEAD] = ks + LNL_AHEAD < kLnlKS ? frag_at(cslot, ks + LNL_AHEAD) : frag_at(nslot, ks + LNL_AHEAD - kLnlKS);
-      if (ks == kLnlKS / 2 + 1 && have_prev) {
+      if (ks == kLnlKS / 2 + 1 && have_prev && !(LNL_ABLATE & 16)) {
         pk = lnl_pack_tile<T>(oth, stage, lane);
         pk_dst = row_dst + (tile - 1) * 64;
+        if (LNL_ABLATE & 512) pk_dst = (char*)g.y + ((pk_dst - (char*)g.y) & 0xFFFF0) ;
       }
-      if (ks == kLnlKS / 2 + 6) bias_into(oth, tile + 1 == g.n_tiles ? 0 : tile + 1);
+      if (ks == kLnlKS / 2 + 6 && !(LNL_ABLATE & 32)) bias_into(oth, tile + 1 == g.n_tiles ? 0 : tile + 1);
 #ifdef LNL_TRACE_FINE
       if (ks % 4 == 3 && ks != kLnlKS / 2 - 1) LNL_MARK(20 + ks / 4);
 #endif
@@ -350,16 +430,17 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
     ++tile;
   };
   auto store_packed = [&]() {
-    if (ok_lo) gstore16(pk_dst, pk.lo);
-    if (ok_hi) gstore16(pk_dst + 16 * g.ldy * 2, pk.hi);
+    if (ok_lo) lnl_gstore(pk_dst, pk.lo);
+    if (ok_hi) lnl_gstore(pk_dst + 16 * g.ldy * 2, pk.hi);
   };
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();      // the first tile is in the ring
   int left = nsteps;
+  bool preloaded = false;
   while (left > 0) {
     LNL_MARK(2);
-    lnl_load_rows<T>(g, blk, gam, bet, wave, lane, xf);
+    lnl_load_rows<T>(g, blk, gam, bet, wave, lane, xf, preloaded, stage);
     LNL_MARK(3);
     const int64_t row = blk * kLnlBlockRows + wave * 32 + (lane >> 2);      // the lane's rows at store time: row, row + 16
     const bool live = !(LNL_ABLATE & 1) || g.eps == 12345.f;
@@ -369,24 +450,40 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
     int nt = g.n_tiles - tile;
     if (nt > left) nt = left;
     left -= nt;
+    // another block follows in this run: its rows are requested during this block's last tile
+    const char* xn = nullptr;
+    if (LNL_PRELOAD && left > 0) {
+      if (!LNL_X_LINES) xn = lnl_row_ptr(g, blk + 1, wave, lane);
+      else if ((blk + 2) * kLnlBlockRows <= g.rows)      // (a last, partial block is requested when its turn comes, rows clamped)
+        xn = (const char*)g.x + ((blk + 1) * kLnlBlockRows + wave * 32 + (lane >> 3)) * g.ldx * 2 + 16 * (lane & 7);
+    }
+    preloaded = xn != nullptr;
     bias_into(acc[0], tile);
 #pragma unroll
     for (int i = 0; i < LNL_AHEAD; ++i) wf[i] = frag_at(cslot, i);
     n_stores = (__builtin_amdgcn_ballot_w64(ok_lo) != 0) + (__builtin_amdgcn_ballot_w64(ok_hi) != 0);
-    step(acc[0], acc[1], false, false, row_dst);
-    int i = 1;
-    for (; i + 1 < nt; i += 2) {
-      step(acc[1], acc[0], true, i > 1, row_dst);
-      step(acc[0], acc[1], true, true, row_dst);
+    const std::false_type reg{};
+    const std::true_type pre{};
+    const int n_reg = xn ? nt - 1 : nt;     // tiles on the regular step; the block's last one requests the next block's rows
+    int k = 0;
+    if (n_reg > 0) {
+      step(acc[0], acc[1], false, false, row_dst, nullptr, reg);
+      for (k = 1; k + 1 < n_reg; k += 2) {
+        step(acc[1], acc[0], true, k > 1, row_dst, nullptr, reg);
+        step(acc[0], acc[1], true, true, row_dst, nullptr, reg);
+      }
+      if (k < n_reg) {
+        step(acc[1], acc[0], true, k > 1, row_dst, nullptr, reg);
+        ++k;
+      }
     }
-    if (i < nt) {
-      step(acc[1], acc[0], true, i > 1, row_dst);
-      if (nt > 1) store_packed();
-      pk = lnl_pack_tile<T>(acc[1], stage, lane);
-    } else {
-      if (nt > 1) store_packed();
-      pk = lnl_pack_tile<T>(acc[0], stage, lane);
+    if (xn) {
+      if (k & 1) step(acc[1], acc[0], k > 0, k > 1, row_dst, xn, pre);
+      else step(acc[0], acc[1], k > 0, k > 1, row_dst, xn, pre);
+      ++k;
     }
+    if (nt > 1) store_packed();
+    pk = (k & 1) ? lnl_pack_tile<T>(acc[0], stage, lane) : lnl_pack_tile<T>(acc[1], stage, lane);
     pk_dst = row_dst + (tile - 1) * 64;
     store_packed();
     if (tile == g.n_tiles) { tile = 0; ++blk; }
