@@ -141,7 +141,7 @@ HSTU_DEV const char* lnl_row_ptr(const LnLinearArgs& g, int64_t blk, int wave, i
   return (const char*)g.x + ((row < g.rows ? row : g.rows - 1) * g.ldx + 8 * (lane >> 5)) * 2;
 }
 
-template <typename T>
+template <typename T, bool NORMED>
 HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam, const float* bet, int wave, int lane,
                             u32x4 (&xf)[kLnlKS], bool preloaded, char* stage) {
   using DT = LnlDot<T>;
@@ -237,13 +237,31 @@ HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam
       o[j] = Elem<T>::pk2(__builtin_fmaf(t0, ga, ba), __builtin_fmaf(t1, gb, bb));
     }
     xf[ks] = o;
+    asm volatile("" : "+v"(xf[ks]));     // computed HERE: left to itself the compiler sinks the arithmetic towards the MFMAs and keeps the table values (spilled) until then
     if (ks % 2 == 1) __builtin_amdgcn_sched_barrier(0);   // or the scheduler hoists all 128 table reads (512 registers)
   }
 #ifndef LNL_TRACE
-  if (g.normed && ok) {
-    char* np = (char*)g.normed + (row * g.ldn + 8 * h) * 2;
+  if (NORMED) {
+    if (LNL_X_LINES) {
+      // the way the rows came in, backwards: each 128-byte column chunk crosses the staging and leaves as whole lines
+      const int pr = lane >> 3, pp = lane & 7;
 #pragma unroll
-    for (int ks = 0; ks < kLnlKS; ++ks) gstore16(np + ks * 32, xf[ks]);
+      for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *LDS_PTR(u32x4, stage + m * 128 + (((2 * j + h) ^ ((m >> 1) & 7)) << 4)) = xf[4 * c + j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 8 * q + pr;
+          const u32x4 v = *LDS_PTR(const u32x4, stage + r * 128 + ((pp ^ ((r >> 1) & 7)) << 4));
+          const int64_t gr = blk * kLnlBlockRows + wave * 32 + r;
+          if (gr < g.rows) lnl_gstore((char*)g.normed + (gr * g.ldn + 64 * c + 8 * pp) * 2, v);
+        }
+      }
+    } else if (ok) {
+      char* np = (char*)g.normed + (row * g.ldn + 8 * h) * 2;
+#pragma unroll
+      for (int ks = 0; ks < kLnlKS; ++ks) gstore16(np + ks * 32, xf[ks]);
+    }
   }
 #endif
 }
@@ -284,7 +302,8 @@ HSTU_DEV LnlPacked lnl_pack_tile(const f32x16& acc, char* stage, int lane) {
   return k;
 }
 
-template <typename T>
+// NORMED: the instantiation that also writes the normalised rows (its extra addressing would cost the other one 8 spilled registers)
+template <typename T, bool NORMED>
 __global__ __launch_bounds__(kLnlThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
   extern __shared__ __attribute__((aligned(1024))) char lnl_smem[];
@@ -440,7 +459,7 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
   bool preloaded = false;
   while (left > 0) {
     LNL_MARK(2);
-    lnl_load_rows<T>(g, blk, gam, bet, wave, lane, xf, preloaded, stage);
+    lnl_load_rows<T, NORMED>(g, blk, gam, bet, wave, lane, xf, preloaded, stage);
     LNL_MARK(3);
     const int64_t row = blk * kLnlBlockRows + wave * 32 + (lane >> 2);      // the lane's rows at store time: row, row + 16
     const bool live = !(LNL_ABLATE & 1) || g.eps == 12345.f;
@@ -493,7 +512,11 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
 template <typename T>
 static int launch_ln_linear(const LnLinearArgs& g, hipStream_t st) {
   const int smem = lnl_smem_bytes(g.n);
-  auto kern = hstu_ln_linear_fwd_kernel<T>;
+#ifdef LNL_TRACE
+  auto kern = hstu_ln_linear_fwd_kernel<T, false>;
+#else
+  auto kern = g.normed ? hstu_ln_linear_fwd_kernel<T, true> : hstu_ln_linear_fwd_kernel<T, false>;
+#endif
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "ln_linear_fwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
   static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();

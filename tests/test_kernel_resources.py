@@ -77,6 +77,9 @@ def test_no_kernel_spills_or_uses_scratch():
     # The short-sequence research backward (one workgroup per CU, one wave per SIMD: 344 registers incl. AGPRs) parks one
     # 8-byte value in scratch at entry (no register spilled in the loops' bodies)
     bounded.update({"hstu_attn_bwd_solo_bias_kernel": 0})
+    # The fused LayerNorm + projection kernel's instantiation that also writes the normalised rows (backward's recompute): 8
+    # registers of its extra addressing live in scratch across the row prologue; the forward's instantiation may not spill.
+    bounded.update({"hstu_ln_linear_fwd_kernelIDF16bLb1E": 8, "hstu_ln_linear_fwd_kernelIDF16_Lb1E": 8})
     bad = {k: v for k, v in ks.items() if (v["spill"] or v["scratch"]) and "hstu" in k and not any(a in k for a in accepted)
            and not any(b in k and v["spill"] <= n for b, n in bounded.items())}
     assert not bad, f"kernels with register spills / scratch: {bad}"
@@ -92,6 +95,8 @@ def test_hot_kernels_stay_under_their_occupancy_limits():
     assert fwd[0]["vgpr"] <= 168, fwd            # 3 waves per SIMD (512 / 3, allocation granule 8)
     assert fold[0]["vgpr"] <= 256, fold          # 2 waves per SIMD
     assert fold64[0]["vgpr"] <= 256, fold64
+    lnl = find("hstu_ln_linear_fwd_kernelIDF16bLb0E")                  # two waves per SIMD, the rows of x in 128 of the registers
+    assert len(lnl) == 1 and lnl[0]["vgpr"] <= 256 and lnl[0]["spill"] == 0, lnl
 
 
 def test_wide_backward_owns_the_accumulator_file_and_passes_the_asm_lint():
