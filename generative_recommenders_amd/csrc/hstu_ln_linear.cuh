@@ -136,25 +136,26 @@ template <> struct LnlDot<f16_t> {
 // The 32 rows of the calling wave, normalised, as MFMA operand fragments: xf[ks] = elements [16 ks + 8 h, +8) of row
 // `lane & 31` (h = lane >> 5).
 // where lane (m, h) finds its pieces of row m of block `blk` (rows past the end: the last row, never stored)
-HSTU_DEV const char* lnl_row_ptr(const LnLinearArgs& g, int64_t blk, int wave, int lane) {
-  const int64_t row = blk * kLnlBlockRows + wave * 32 + (lane & 31);
+HSTU_DEV const char* lnl_row_ptr(const LnLinearArgs& g, int64_t row0, int lane) {
+  const int64_t row = row0 + (lane & 31);
   return (const char*)g.x + ((row < g.rows ? row : g.rows - 1) * g.ldx + 8 * (lane >> 5)) * 2;
 }
 
-template <typename T, bool NORMED>
-HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam, const float* bet, int wave, int lane,
-                            u32x4 (&xf)[kLnlKS], bool preloaded, char* stage) {
+// TAB16: the LayerNorm tables sit in LDS in the I/O type (the two-workgroup arrangement's 80 KiB budget) instead of fp32
+template <typename T, bool NORMED, bool TAB16 = false>
+HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t row0, const float* gam, const float* bet, int lane,
+                            u32x4 (&xf)[kLnlKS], bool preloaded, char* stage, bool x_lines = LNL_X_LINES) {
   using DT = LnlDot<T>;
   const int m = lane & 31, h = lane >> 5;
-  const int64_t row = blk * kLnlBlockRows + wave * 32 + m;
+  const int64_t row = row0 + m;
   const bool ok = row < g.rows;
-  const char* xp = lnl_row_ptr(g, blk, wave, lane);
-  if (preloaded && !LNL_X_LINES) {
+  const char* xp = lnl_row_ptr(g, row0, lane);
+  if (preloaded && !x_lines) {
     // the raw rows are already on their way: requested fragment by fragment under the last tile of the block before
   } else if (LNL_ABLATE & 64) {
 #pragma unroll
     for (int ks = 0; ks < kLnlKS; ++ks) asm volatile("" : "=v"(xf[ks]));
-  } else if (LNL_X_LINES) {
+  } else if (x_lines) {
     // instruction 4 c + q fetches bytes [128 c, 128 c + 128) of the rows 8 q .. 8 q + 7 of the wave: lane L = (row 8 q + (L >> 3),
     // piece L & 7) -- eight whole lines per instruction instead of 32 quarter lines.  Each 128-byte column chunk (4 MFMA steps)
     // then crosses the wave's staging: piece p of row r sits at slot p ^ ((r >> 1) & 7) of the row (conflict-free for the
@@ -163,7 +164,7 @@ HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam
     const char* rp[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int64_t r = blk * kLnlBlockRows + wave * 32 + 8 * q + pr;
+      const int64_t r = row0 + 8 * q + pr;
       rp[q] = (const char*)g.x + (r < g.rows ? r : g.rows - 1) * g.ldx * 2 + 16 * pp;
     }
     if (!preloaded) {      // (else: requested under the last tile of the block before, the same way)
@@ -226,8 +227,17 @@ HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam
   const float* bp = bet + 8 * h;
 #pragma unroll
   for (int ks = 0; ks < kLnlKS; ++ks) {
-    const f32x4 g0 = *LDS_PTR(const f32x4, gp + 16 * ks), g1 = *LDS_PTR(const f32x4, gp + 16 * ks + 4);
-    const f32x4 b0 = *LDS_PTR(const f32x4, bp + 16 * ks), b1 = *LDS_PTR(const f32x4, bp + 16 * ks + 4);
+    f32x4 g0, g1, b0, b1;
+    if constexpr (TAB16) {
+      const u32x4 gw = *LDS_PTR(const u32x4, (const T*)gam + 8 * h + 16 * ks), bw = *LDS_PTR(const u32x4, (const T*)bet + 8 * h + 16 * ks);
+      g0 = f32x4{DT::lo(gw[0]), DT::hi(gw[0]), DT::lo(gw[1]), DT::hi(gw[1])};
+      g1 = f32x4{DT::lo(gw[2]), DT::hi(gw[2]), DT::lo(gw[3]), DT::hi(gw[3])};
+      b0 = f32x4{DT::lo(bw[0]), DT::hi(bw[0]), DT::lo(bw[1]), DT::hi(bw[1])};
+      b1 = f32x4{DT::lo(bw[2]), DT::hi(bw[2]), DT::lo(bw[3]), DT::hi(bw[3])};
+    } else {
+      g0 = *LDS_PTR(const f32x4, gp + 16 * ks), g1 = *LDS_PTR(const f32x4, gp + 16 * ks + 4);
+      b0 = *LDS_PTR(const f32x4, bp + 16 * ks), b1 = *LDS_PTR(const f32x4, bp + 16 * ks + 4);
+    }
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -242,7 +252,7 @@ HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam
   }
 #ifndef LNL_TRACE
   if (NORMED) {
-    if (LNL_X_LINES) {
+    if (x_lines) {
       // the way the rows came in, backwards: each 128-byte column chunk crosses the staging and leaves as whole lines
       const int pr = lane >> 3, pp = lane & 7;
 #pragma unroll
@@ -253,7 +263,7 @@ HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t blk, const float* gam
         for (int q = 0; q < 4; ++q) {
           const int r = 8 * q + pr;
           const u32x4 v = *LDS_PTR(const u32x4, stage + r * 128 + ((pp ^ ((r >> 1) & 7)) << 4));
-          const int64_t gr = blk * kLnlBlockRows + wave * 32 + r;
+          const int64_t gr = row0 + r;
           if (gr < g.rows) lnl_gstore((char*)g.normed + (gr * g.ldn + 64 * c + 8 * pp) * 2, v);
         }
       }
@@ -459,7 +469,7 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
   bool preloaded = false;
   while (left > 0) {
     LNL_MARK(2);
-    lnl_load_rows<T, NORMED>(g, blk, gam, bet, wave, lane, xf, preloaded, stage);
+    lnl_load_rows<T, NORMED>(g, blk * kLnlBlockRows + wave * 32, gam, bet, lane, xf, preloaded, stage);
     LNL_MARK(3);
     const int64_t row = blk * kLnlBlockRows + wave * 32 + (lane >> 2);      // the lane's rows at store time: row, row + 16
     const bool live = !(LNL_ABLATE & 1) || g.eps == 12345.f;
@@ -472,7 +482,7 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
     // another block follows in this run: its rows are requested during this block's last tile
     const char* xn = nullptr;
     if (LNL_PRELOAD && left > 0) {
-      if (!LNL_X_LINES) xn = lnl_row_ptr(g, blk + 1, wave, lane);
+      if (!LNL_X_LINES) xn = lnl_row_ptr(g, (blk + 1) * kLnlBlockRows + wave * 32, lane);
       else if ((blk + 2) * kLnlBlockRows <= g.rows)      // (a last, partial block is requested when its turn comes, rows clamped)
         xn = (const char*)g.x + ((blk + 1) * kLnlBlockRows + wave * 32 + (lane >> 3)) * g.ldx * 2 + 16 * (lane & 7);
     }

@@ -11,7 +11,7 @@ from collections import defaultdict
 def key(name):
     if name.startswith("Cijk") or name.startswith("Custom_Cijk"):
         return "GEMM " + name.split("_MT")[0][:40] + " MT" + name.split("_MT")[1].split("_")[0] if "_MT" in name else "GEMM " + name[:60]
-    for k in ("hstu_attn_bwd_fold_kernel", "hstu_attn_fwd_kernel", "norm_mul_fwd_gn_kernel", "norm_mul_bwd_gn_kernel", "layer_norm_fwd_kernel",
+    for k in ("hstu_ln_linear_fwd_kernel", "hstu_attn_bwd_fold_kernel", "hstu_attn_fwd_kernel", "norm_mul_fwd_gn_kernel", "norm_mul_bwd_gn_kernel", "layer_norm_fwd_kernel",
               "layer_norm_bwd_kernel", "reduce_partials_kernel", "reduce_kernel", "multi_tensor_apply", "copyBuffer", "elementwise"):
         if k in name:
             return k
