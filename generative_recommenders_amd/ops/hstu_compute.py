@@ -126,6 +126,18 @@ def _ln_uvqk(x, norm_weight, norm_bias, eps, w, kmajor, bias, want_normed):
     return _uvqk_gemm(normed_x, w, kmajor, bias), normed_x, mean, rstd
 
 
+def _recompute_uvqk(x, norm_weight, norm_bias, eps, w, kmajor, bias, normed_x):
+    """backward's (uvqk, normed_x) when uvqk was not kept: by the SAME kernel as forward -- the fused kernel and hipBLASLt sum
+    in different orders, and a recomputed u that differs from forward's in the last bit makes the one-node and two-node layers
+    disagree -- so where forward took the fused kernel it runs again here even if normed_x was kept (it is the faster call anyway)"""
+    if _LN_LINEAR and kmajor and _launch.ln_linear_supported(x, w.shape[0]):
+        uvqk, nx, _, _ = _launch.ln_linear_fwd(x, norm_weight, norm_bias, eps, w, bias, want_normed=normed_x is None)
+        return uvqk, (nx if normed_x is None else normed_x)
+    if normed_x is None:
+        normed_x, _, _ = _launch.layer_norm_fwd(x, norm_weight, norm_bias, eps)
+    return _uvqk_gemm(normed_x, w, kmajor, bias), normed_x
+
+
 def _uvqk_dgrad(duvqk: torch.Tensor, w: torch.Tensor, kmajor: bool) -> torch.Tensor:
     return torch.mm(duvqk, w) if kmajor else torch.mm(duvqk, w.t())
 
@@ -272,12 +284,10 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         normed_x = rest.pop(0) if ctx.keep_normed else None
         uvqk = rest.pop(0) if ctx.keep_uvqk else None
         eps, H, A, Hd, N, alpha, w, c = ctx.meta
-        if normed_x is None and uvqk is None:
-            uvqk, normed_x, _, _ = _ln_uvqk(x, nw, nb, eps, W, ctx.kmajor, beta, want_normed=True)
-        if normed_x is None:
-            normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, eps)
         if uvqk is None:
-            uvqk = _uvqk_gemm(normed_x, W, ctx.kmajor, beta)
+            uvqk, normed_x = _recompute_uvqk(x, nw, nb, eps, W, ctx.kmajor, beta, normed_x)
+        elif normed_x is None:
+            normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, eps)
         hv, ha = Hd * H, A * H
         v = uvqk[:, hv : 2 * hv].view(-1, H, Hd)
         q = uvqk[:, 2 * hv : 2 * hv + ha].view(-1, H, A)
@@ -357,12 +367,10 @@ class _STULayerFunction(torch.autograd.Function):
         uvqk = rest.pop(0) if ctx.keep[1] else None
         y = rest.pop(0) if ctx.keep[2] else None
         in_eps, out_eps, H, A, Hd, N, alpha, w, c, cat, gn, p_drop, seed = ctx.meta
-        if normed_x is None and uvqk is None:
-            uvqk, normed_x, _, _ = _ln_uvqk(x, nw, nb, in_eps, W, ctx.kmajor, beta, want_normed=True)
-        if normed_x is None:
-            normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, in_eps)
         if uvqk is None:
-            uvqk = _uvqk_gemm(normed_x, W, ctx.kmajor, beta)
+            uvqk, normed_x = _recompute_uvqk(x, nw, nb, in_eps, W, ctx.kmajor, beta, normed_x)
+        elif normed_x is None:
+            normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, in_eps)
         hv, ha = Hd * H, A * H
         u_pre = uvqk[:, :hv]
         if y is None:
