@@ -237,7 +237,7 @@ def rooflines(att, workload):
 # the other shapes north_star names, run for a few steps after the headline so that the driver's record carries them
 # (M-full-1024: the metric shape at the PER-GPU batch of the 8-GPU metric -- 8192 users over 8 ranks: launch ramp, first prologue
 # and last tail weigh 8x more than at 8192 users per GPU)
-EXTRA_WORKLOADS = [("M-jag", {}), ("M-full-1024", {"workload": "M-full", "users": 1024, "steps": 48}), ("M-full-d64", {"workload": "M-full", "head_dim": 64}),
+EXTRA_WORKLOADS = [("M-jag", {}), ("M-full-1024", {"workload": "M-full", "users": 1024, "steps": 96, "warmup": 20}), ("M-full-d64", {"workload": "M-full", "head_dim": 64}),
                    ("C2", {}), ("C3", {}), ("C3-bias", {})]
 
 
@@ -248,7 +248,7 @@ def extra_workloads(args, rank, world, device):
         a.workload = over.get("workload", name)
         n, h, d, users, _ = WORKLOADS[a.workload]
         a.max_seq_len, a.heads, a.head_dim, a.users_per_gpu = n, h, over.get("head_dim", d), over.get("users", users)
-        a.steps, a.warmup = over.get("steps", args.extra_steps), over.get("steps", 24) // 8   # (sub-millisecond steps: more of them, or the loop is over before the clocks have settled)
+        a.steps, a.warmup = over.get("steps", args.extra_steps), over.get("warmup", over.get("steps", 24) // 8)   # (sub-millisecond steps: more of them, or the loop is over before the clocks have settled)
         a.sort_by_length = a.workload == "C3"
         try:
             att = attention_section(a, rank, world, device)

@@ -36,16 +36,22 @@ def hstu_compute_uqvk(
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """LN_affine(x) @ W + b, split as [u, v, q, k], SiLU on u only."""
     del kernel
-    norm_weight, norm_bias, uvqk_weight, uvqk_bias = (t.to(x.dtype) for t in (norm_weight, norm_bias, uvqk_weight, uvqk_bias))
-    normed_x = layer_norm(x, weight=norm_weight, bias=norm_bias, eps=norm_eps)
-    # (autograd's own nodes.  The same GEMM kernel as the fused layer's -- linear() on a K-contiguous weight -- so that the
-    # K / V rows a delta call appends to a cache are bit-identical to the ones the prefill wrote)
-    if _UVQK_LINEAR and normed_x.is_cuda:
-        tracked = torch.is_grad_enabled() and uvqk_weight.requires_grad
-        wt = uvqk_weight.t().contiguous() if tracked else _kmajor(uvqk_weight, normed_x.dtype)
-        uvqk = torch.nn.functional.linear(normed_x, wt.to(normed_x.dtype), uvqk_bias.to(normed_x.dtype))
+    if _LN_LINEAR and _UVQK_LINEAR and x.is_cuda and x.dim() == 2 and _launch.ln_linear_supported(x, uvqk_weight.shape[1]):
+        # the fused LayerNorm + projection kernel (one autograd node), as the STU layer's nodes use it: the K / V rows a delta
+        # call appends to a cache are then bit-identical to the ones the prefill wrote (a row's result does not depend on its
+        # neighbours in the batch)
+        uvqk = _LnUvqkFunction.apply(x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, norm_eps)
     else:
-        uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
+        norm_weight, norm_bias, uvqk_weight, uvqk_bias = (t.to(x.dtype) for t in (norm_weight, norm_bias, uvqk_weight, uvqk_bias))
+        normed_x = layer_norm(x, weight=norm_weight, bias=norm_bias, eps=norm_eps)
+        # (autograd's own nodes.  The same GEMM kernel as the fused layer's -- linear() on a K-contiguous weight -- so that the
+        # K / V rows a delta call appends to a cache are bit-identical to the ones the prefill wrote)
+        if _UVQK_LINEAR and normed_x.is_cuda:
+            tracked = torch.is_grad_enabled() and uvqk_weight.requires_grad
+            wt = uvqk_weight.t().contiguous() if tracked else _kmajor(uvqk_weight, normed_x.dtype)
+            uvqk = torch.nn.functional.linear(normed_x, wt.to(normed_x.dtype), uvqk_bias.to(normed_x.dtype))
+        else:
+            uvqk = torch.addmm(uvqk_bias, normed_x, uvqk_weight)
     u, v, q, k = torch.split(
         uvqk, [hidden_dim * num_heads, hidden_dim * num_heads, attn_dim * num_heads, attn_dim * num_heads], dim=1
     )
@@ -54,6 +60,33 @@ def hstu_compute_uqvk(
     k = k.view(-1, num_heads, attn_dim)
     v = v.view(-1, num_heads, hidden_dim)
     return u, q, k, v
+
+
+class _LnUvqkFunction(torch.autograd.Function):
+    """uvqk = LayerNorm(x) @ W + b by the fused kernel (csrc/hstu_ln_linear.cuh); backward = the projection's three GEMM-shaped
+    gradients (hipBLASLt) + the layer-norm backward kernel, normed_x recomputed by the row kernel (as the STU layer's nodes do)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, eps):
+        ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
+        nw, nb, beta = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_bias))
+        w, kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
+        uvqk, _, mean, rstd = _ln_uvqk(x, nw, nb, eps, w, kmajor, beta, want_normed=False)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, w)
+        ctx.kmajor, ctx.eps = kmajor, eps
+        return uvqk
+
+    @staticmethod
+    def backward(ctx, duvqk):
+        x, nw, nb, mean, rstd, w = ctx.saved_tensors
+        duvqk = duvqk.contiguous()
+        normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, ctx.eps)
+        dt = ctx.param_dtypes
+        d_normed = _uvqk_dgrad(duvqk, w, ctx.kmajor)
+        dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
+        dbeta = duvqk.sum(dim=0, dtype=torch.float32 if dt[3] == torch.float32 else None)
+        dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
+        return dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, dbeta.to(dt[3]), None
 
 
 class _SiluFunction(torch.autograd.Function):

@@ -184,3 +184,53 @@ def test_two_workgroups_per_cu_arrangement_matches():
             outs[split] = [torch.load(os.path.join(td, f"y{split}.{rows}.pt")) for rows in (4099, 70000, 257)]
         for a, b in zip(outs["0"], outs["1"]):
             assert torch.equal(a, b)
+
+
+def test_public_uvqk_op_runs_the_fused_kernel_forward_backward_and_row_results_do_not_depend_on_the_batch():
+    """`hstu_compute_uqvk` (ops/hstu_compute.py:50-89) at embedding dim 512 with bf16 activations and fp32 master parameters:
+    u, q, k, v and every gradient against fp64 autograd on the same bf16-representable inputs (relative Frobenius: q / k / v
+    2.8e-3 = the bf16 gate of tests/test_compute_gpu.py, u 4.4e-3, gradients 8e-3: four bf16 roundings in the chain); and the rows of a
+    sub-batch are bit-identical to the same rows computed inside the full batch (what makes K / V appended by a delta call
+    equal to what the prefill wrote)"""
+    from generative_recommenders_amd.ops.hstu_compute import hstu_compute_uqvk
+
+    D, H, Hd, A, rows = 512, 4, 128, 128, 777
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(rows, D, generator=g).to(torch.bfloat16)
+    nw0, nb0 = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    W0 = (torch.randn(D, 2 * H * (Hd + A), generator=g) / D**0.5)
+    b0 = 0.1 * torch.randn(2 * H * (Hd + A), generator=g)
+    # parameters as the kernel sees them (cast to bf16 inside the node): the fp64 reference starts from the same values
+    rb = lambda t: t.to(torch.bfloat16).double()
+    cot = [torch.randn(rows, H * Hd, generator=g), torch.randn(rows, H, A, generator=g), torch.randn(rows, H, A, generator=g),
+           torch.randn(rows, H, Hd, generator=g)]
+
+    def run(dev, dt, params):
+        x = (x0.double() if dt == torch.float64 else x0).to(dev).requires_grad_()
+        ps = [p.to(dev).requires_grad_() for p in params]
+        if dt == torch.float64:
+            nx = torch.nn.functional.layer_norm(x, (D,), ps[0], ps[1], 1e-6)
+            uvqk = nx @ ps[2] + ps[3]
+            u, v, q, k = torch.split(uvqk, [H * Hd, H * Hd, H * A, H * A], dim=1)
+            outs = [torch.nn.functional.silu(u), q.reshape(-1, H, A), k.reshape(-1, H, A), v.reshape(-1, H, Hd)]
+        else:
+            outs = list(hstu_compute_uqvk(x, ps[0], ps[1], 1e-6, H, A, Hd, ps[2], ps[3]))
+        loss = sum((o.double() * c.to(dev).double()).sum() for o, c in zip(outs, cot))
+        loss.backward()
+        return [o.detach() for o in outs], [x.grad] + [p.grad for p in ps]
+
+    ref_o, ref_g = run("cpu", torch.float64, [rb(nw0), rb(nb0), rb(W0), rb(b0)])
+    got_o, got_g = run(DEV, torch.bfloat16, [nw0, nb0, W0, b0])
+    oerr = {name: _rel(a, b.numpy()) for name, a, b in zip(("u", "q", "k", "v"), got_o, ref_o)}
+    assert all(a.dtype == torch.bfloat16 for a in got_o)
+    # q, k, v: two bf16 roundings on the way (normed_x, the projection's output); u a third (SiLU's output): sqrt(3) x 1.66e-3
+    assert max(oerr["q"], oerr["k"], oerr["v"]) <= 2.8e-3 and oerr["u"] <= 4.4e-3, oerr
+    errs = {name: _rel(a, b.numpy()) for name, a, b in zip(("dx", "dnorm_weight", "dnorm_bias", "dW", "dbias"), got_g, ref_g)}
+    assert all(e <= 8e-3 for e in errs.values()), errs
+    assert got_g[3].dtype == torch.float32          # fp32 master weight: its gradient arrives in fp32
+    with torch.no_grad():
+        sub = torch.arange(40, 300, 7)
+        full = hstu_compute_uqvk(x0.to(DEV), nw0.to(DEV), nb0.to(DEV), 1e-6, H, A, Hd, W0.to(DEV), b0.to(DEV))
+        part = hstu_compute_uqvk(x0[sub].to(DEV), nw0.to(DEV), nb0.to(DEV), 1e-6, H, A, Hd, W0.to(DEV), b0.to(DEV))
+        for f, p in zip(full, part):
+            assert torch.equal(f[sub.to(DEV)], p)
