@@ -51,6 +51,9 @@
 #ifndef FOLD_DMA_FAST
 #define FOLD_DMA_FAST 1    // LDS-DMA source addresses as scalar base + 32-bit lane offset (3 instead of ~20 VALU per chunk)
 #endif
+#ifndef FOLD_NT_STORES
+#define FOLD_NT_STORES 1   // non-temporal hint on 1: the dk / dv copy-out (-0.2 .. -0.9 %), 2: the dQ stores (+2.7 %: off); profiles/r04_fold_nt_stores.txt
+#endif
 #ifndef FOLD_DQ32
 #define FOLD_DQ32 1        // head dim 128 without an attention window: the dQ GEMM as 32x32x16 chains, wave = (feature block, side)
 #endif
@@ -416,7 +419,10 @@ HSTU_DEV void fold_copy_out(const char* __restrict__ tile, char* gtile, int64_t 
     const int row = u / UPR, unit = u % UPR;
     u32x4 v = *LDS_PTR(const u32x4, tile + tile_off<UPR>(row, unit));
     if (FOLD_PARK_SWAP && UPR >= 16 && ((row >> 1) & 1)) v = u32x4{v[2], v[3], v[0], v[1]};     // (see fold_park_tile)
-    if (row < rows_valid && (!(FOLD_ABLATE & 2) || row_stride_bytes == -12345)) gstore16(gtile + row * row_stride_bytes + unit * 16, v);
+    if (row < rows_valid && (!(FOLD_ABLATE & 2) || row_stride_bytes == -12345)) {
+      if (FOLD_NT_STORES & 1) gstore16_nt(gtile + row * row_stride_bytes + unit * 16, v);
+      else gstore16(gtile + row * row_stride_bytes + unit * 16, v);
+    }
   }
 }
 
@@ -682,8 +688,13 @@ HSTU_DEV void fold_dq_phase32(const HstuAttnBwdParams& bp, const MaskCtx& mc, co
   const int qrow = q0 + n32;
   if (qrow < mc.len && (!(FOLD_ABLATE & 1) || bp.total_rows == -12345)) {
     char* dst = (char*)bp.dq + ((off0 + qrow) * bp.dq_row_stride + (int64_t)hd * bp.dq_head_stride) * C::EB + (32 * db + 8 * hf) * C::EB;
-    gstore16(dst, u32x4{g[0][0], g[0][1], g[1][0], g[1][1]});
-    gstore16(dst + 16 * C::EB, u32x4{g[2][0], g[2][1], g[3][0], g[3][1]});
+    if (FOLD_NT_STORES & 2) {
+      gstore16_nt(dst, u32x4{g[0][0], g[0][1], g[1][0], g[1][1]});
+      gstore16_nt(dst + 16 * C::EB, u32x4{g[2][0], g[2][1], g[3][0], g[3][1]});
+    } else {
+      gstore16(dst, u32x4{g[0][0], g[0][1], g[1][0], g[1][1]});
+      gstore16(dst + 16 * C::EB, u32x4{g[2][0], g[2][1], g[3][0], g[3][1]});
+    }
   }
 }
 
