@@ -1,5 +1,11 @@
 // Launcher of the folded backward schedule (hstu_attn_bwd_fold.cuh).
 #pragma once
+// The folded and four-wave backward kernels read every tile of q / k / v / dO exactly once, from one CU: their LDS-DMA requests
+// carry the non-temporal hint (-0.5 % M-full, -1.4 % M-jag, bit-identical: profiles/r04_dma_nt.txt).  The forward must NOT: its
+// query blocks share a problem's K / V through L2 (+18..24 % with the hint).
+#ifndef HSTU_DMA_NT
+#define HSTU_DMA_NT 1
+#endif
 #include "capi_internal.h"
 #include "hstu_attn_bwd_quad.cuh"
 

@@ -92,7 +92,7 @@ struct FoldCfg {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 HSTU_DEV void dma16_asm(const char* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" HSTU_DMA_POLICY ::"v"(g), "s"(lds_base) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 

@@ -121,11 +121,20 @@ HSTU_DEV void tile_lds_write(const u32x4 (&reg)[NU], char* tile, int row0, int l
 // kernel orders the consumers itself (counted vmcnt + barrier at the top of every tile).
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+// HSTU_DMA_NT: the non-temporal hint on the tile requests -- every byte of q / k / v / dO is read once, by one CU
+#ifndef HSTU_DMA_NT
+#define HSTU_DMA_NT 0
+#endif
+#if HSTU_DMA_NT
+#define HSTU_DMA_POLICY " nt"
+#else
+#define HSTU_DMA_POLICY ""
+#endif
 HSTU_DEV void dma16_saddr_asm(uint32_t off, const char* base, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" HSTU_DMA_POLICY ::"v"(off), "s"(base), "s"(lds_base) : "memory", "m0");
 }
 HSTU_DEV void dma16_vaddr_asm(const char* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" HSTU_DMA_POLICY ::"v"(g), "s"(lds_base) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
