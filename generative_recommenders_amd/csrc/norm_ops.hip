@@ -12,6 +12,11 @@
 #include "hstu_common.cuh"
 #include "capi_internal.h"
 
+#ifndef NORM_NT
+#define NORM_NT 2      // non-temporal hint on the row kernels' 16-byte loads (1) / stores (2) of 16-bit rows: stores on (layer norm fwd 81 -> 68 us,
+                       // SiLU fwd 81 -> 62 us, the others -1..-3 %, layer step unchanged); loads mixed (norm_mul bwd +6 %): off.  profiles/r04_norm_nt.txt
+#endif
+
 namespace hstu {
 // narrow / wide instances of every kernel and launcher (norm_kernels.inc)
 namespace nw1 {
