@@ -11,6 +11,10 @@
 #include "hstu_common.cuh"
 #include "capi_internal.h"
 
+#ifndef JAGGED_NT
+#define JAGGED_NT 0     // non-temporal hint on the byte movers' loads (1) / stores (2)
+#endif
+
 namespace hstu {
 
 constexpr int kRowsPerBlock = 16;
@@ -29,8 +33,9 @@ HSTU_DEV void copy_row(char* dst, const char* src, int row_bytes, int t, int nth
   typedef typename VecT<V>::type vt;
   const int n = row_bytes / V;
   for (int i = t; i < n; i += nthr) {
-    vt x = src ? reinterpret_cast<const vt*>(src)[i] : vt{};
-    reinterpret_cast<vt*>(dst)[i] = x;
+    vt x = !src ? vt{} : (JAGGED_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const vt*>(src) + i) : reinterpret_cast<const vt*>(src)[i];
+    if (JAGGED_NT & 2) __builtin_nontemporal_store(x, reinterpret_cast<vt*>(dst) + i);
+    else reinterpret_cast<vt*>(dst)[i] = x;
   }
 }
 
