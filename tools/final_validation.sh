@@ -10,9 +10,9 @@ timeout 1800 python -m pytest tests -q -m gpu --durations=5 2>&1 | tail -12
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
 echo "== bench default"
-timeout 900 python bench.py > gpurun_out/${TAG}/bench_default.json 2> gpurun_out/${TAG}/bench_default.err; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/${TAG}/bench_default.json').read().strip().splitlines()[-1])
+timeout 900 python bench.py > gpurun_out/${TAG}/bench_default.json 2> gpurun_out/${TAG}/bench_default.err; TAG=${TAG} python - <<'PY'
+import json, os
+d=json.loads(open('gpurun_out/' + os.environ['TAG'] + '/bench_default.json').read().strip().splitlines()[-1])
 print('value', round(d['value']), 'ms/step', d['ms_per_step'], 'fwd', d['roofline_fwd']['avg_launch_ms'], d['roofline_fwd']['frac'], 'bwd', d['roofline']['avg_launch_ms'], d['roofline']['frac'], 'both', d.get('roofline_fwd_bwd',{}).get('frac'))
 for k,v in d['extra_workloads'].items(): print(' ', k, {x: v.get(x) for x in ('fwd_ms','bwd_ms','frac_fwd','frac_bwd','frac_fwd_bwd')})
 L=d.get('layer'); print('layer', {k: L.get(k) for k in ('ms_per_step','error')} , {k: L[k]['ms_per_step'] for k in ('two_node_layers','dropout_off','no_recompute') if k in L}, L.get('projections'))
