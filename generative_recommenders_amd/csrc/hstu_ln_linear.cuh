@@ -4,18 +4,25 @@
 //   kernels replaced: ops/triton/triton_layer_norm.py:77-309 + ops/triton/triton_addmm.py:185-340.
 //
 // The contraction length is the layer's embedding dim, K = 512: a row of x is 1 KiB, so a WAVE keeps 32 complete rows
-// in registers (128 VGPRs, already in the layout of the MFMA operand) -- x is read from memory exactly once, the row
-// statistics and the affine are applied in registers, and normed_x never exists in memory unless asked for.  A workgroup
+// in registers (128 VGPRs, in the layout of the MFMA operand) -- x is read from memory exactly once (as whole 128-byte
+// lines, turned into fragments through 4 KiB of wave-private LDS), the row statistics and the affine are applied in
+// registers, and normed_x never exists in memory unless asked for (the NORMED instantiation: backward's recompute).  A workgroup
 // (8 waves = 256 rows, two waves per SIMD) then walks the weight: W is streamed, 32 output columns at a time (32 x 512,
 // K-contiguous rows = 32 KiB), through a ring of LDS tiles filled by LDS-DMA; every wave multiplies every tile by its
 // own rows.  Traffic per 256 x 32 outputs: one 32 KiB tile from L2 (16 B/clk/CU with the MFMA pipe saturated; W is 2 MiB
 // and stays in every XCD's L2) and one ds_read_b128 per MFMA -- against A AND B panels for a square tile.
 //
 // The product is formed transposed (W supplies the MFMA's A operand, x its B operand): a lane then holds, for ONE row
-// of y, four runs of 4 consecutive columns; v_permlane32_swap pairs the half-waves' runs into 16-byte stores (64
-// contiguous bytes per row and tile).  The bias enters as the accumulator's start value (the first MFMA of a chain takes
-// its C operand from the bias registers: no add, no zeroing); accumulators ping-pong, so tile t is converted and stored
-// under the MFMAs of tile t + 1.
+// of y, four runs of 4 consecutive columns; v_permlane32_swap pairs the half-waves' runs into 16-byte pieces, which cross
+// the wave's LDS staging and leave as 16 rows x 64 contiguous bytes per (non-temporal) store.  The bias enters as the
+// accumulator's start value (the first MFMA of a chain takes its C operand from the bias registers: no add, no zeroing);
+// accumulators ping-pong: tile t is packed under the MFMAs of tile t + 1 and stored under those of tile t + 2.  One
+// barrier per tile in the MIDDLE of its chain, behind a counted vmcnt (lnl step): the next tile has landed, the previous
+// tile's slot is requested again, and the wave's six memory instructions of a step are spread over the chain.
+//
+// 421-445 us at 204,800 x 512 -> 2048 (layer norm + hipBLASLt: 82 + 577..607); what bounds it, and the arrangements
+// that lost (rows of the next block requested early: LNL_PRELOAD; two workgroups per CU: hstu_ln_linear2.cuh):
+// docs/EXPERIMENTS.md R4.8.
 //
 // Work is cut into (row block, column tile) units, dealt to the persistent workgroups (one per CU) as CONTIGUOUS runs
 // of equal length: 204,800 rows = 800 blocks would leave a quarter of the chip idle in the last of 3.1 rounds; 51,200
@@ -43,8 +50,8 @@ namespace hstu {
 #define LNL_DRAIN_STORES 0 // 1: every step waits for the previous step's stores of y as well (vmcnt(0))
 #endif
 #ifndef LNL_PRELOAD
-#define LNL_PRELOAD 0      // request the next block's rows of x under the last tile of a block (measured: 482 against 448 us -- the
-                           // 32 fragment-shaped loads per lane hold up the wave's other memory instructions and the MFMAs behind them)
+#define LNL_PRELOAD 0      // request the next block's rows of x under the last tile of a block (a step instantiation of its own):
+                           // measured 439-451 against 423-428 us -- memory instructions in the chain hold up the MFMAs behind them
 #endif
 #ifndef LNL_NT_STORES
 #define LNL_NT_STORES 1    // y leaves with the non-temporal hint (443 -> 421 us)
