@@ -289,10 +289,13 @@ HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t row0, const float* ga
 // requests of whole 64-byte row segments, and the stores then hold up the weight requests queued behind them (timeline in
 // docs/EXPERIMENTS.md R4.8) -- so the pieces take a turn through a wave-private 2 KiB of LDS and come back row-major: lane L
 // gets piece L & 3 of rows L >> 2 (.lo) and 16 + (L >> 2) (.hi); an instruction then writes 16 rows x 64 contiguous bytes.
-// Piece c of row m sits at slot c ^ ((m >> 2) & 3) of its 64-byte row: conflict-free for the ds_write_b128 lane groups (8
-// consecutive rows, one piece) and the ds_read_b128 groups (4 rows x 4 pieces).  LDS operations of one wave execute in order.
+// Piece c of row m sits at slot c ^ ((m >> 1) & 3) of its 64-byte row: conflict-free for the ds_write_b128 lane groups (8
+// consecutive rows, one piece; stores bank by 32 banks = a 128-byte window) and the ds_read_b128 groups (4 rows x 4 pieces; 64 banks).  LDS operations of one wave execute in order.
 struct LnlPacked { u32x4 lo, hi; };
-HSTU_DEV uint32_t lnl_stage_off(int m, int c) { return (uint32_t)(m * 64 + ((c ^ ((m >> 2) & 3)) << 4)); }
+#ifndef LNL_STAGE_SHIFT
+#define LNL_STAGE_SHIFT 1    // (2: the first version's swizzle, two-way conflicts on the stores into the staging)
+#endif
+HSTU_DEV uint32_t lnl_stage_off(int m, int c) { return (uint32_t)(m * 64 + ((c ^ ((m >> LNL_STAGE_SHIFT) & 3)) << 4)); }
 template <typename T>
 HSTU_DEV LnlPacked lnl_pack_tile(const f32x16& acc, char* stage, int lane) {
   typedef Elem<T> E;
