@@ -100,6 +100,29 @@ def test_validation_errors_without_gpu(lib):
     assert lib.hstu_split_2d_jagged(None, None, None, None, None, 0, 0, 0, 1, 1, 4, 0, 0, None) == -1
 
 
+def test_ln_linear_shape_rule_and_validation_without_gpu(lib):
+    """hstu_ln_linear_fwd (ABI v9): which shapes the fused LayerNorm + projection kernel takes, and its argument checks --
+    all before any launch"""
+    BF16, F16, F32 = 0, 1, 2
+    sup = lib.hstu_ln_linear_fwd_supported
+    assert sup(1000, 512, 2048, BF16) == 1 and sup(1, 512, 32, F16) == 1 and sup(10**6, 512, 4096, BF16) == 1
+    assert sup(1000, 512, 2048, F32) == 0            # fp32 activations: layer norm + GEMM
+    assert sup(1000, 256, 2048, BF16) == 0 and sup(1000, 1024, 2048, BF16) == 0     # embedding dims other than 512
+    assert sup(1000, 512, 2000, BF16) == 0 and sup(1000, 512, 4128, BF16) == 0 and sup(1000, 512, 0, BF16) == 0
+    buf = (C.c_char * 4096)()
+    a = (C.addressof(buf) + 15) & ~15
+    call = lambda x=a, ldx=512, w=a, y=a, ldy=2048, normed=None, ldn=0, rows=4, k=512, n=2048, dt=BF16: lib.hstu_ln_linear_fwd(
+        x, ldx, a, a, 1e-6, w, a, y, ldy, normed, ldn, None, None, rows, k, n, dt, None)
+    assert call(rows=0) == 0                          # nothing to do: no launch, no error
+    assert call(x=None) == -1 and b"NULL" in lib.hstu_last_error()
+    assert call(k=256) == -1 and b"k == 512" in lib.hstu_last_error()
+    assert call(dt=F32) == -1 and b"bf16 / fp16" in lib.hstu_last_error()
+    assert call(ldy=2040) == -1 and b"leading dimension" in lib.hstu_last_error()
+    assert call(ldx=516) == -1 and b"multiples of 8" in lib.hstu_last_error()
+    assert call(y=a + 8) == -1 and b"16-byte aligned" in lib.hstu_last_error()
+    assert call(normed=a, ldn=100) == -1 and b"leading dimension" in lib.hstu_last_error()
+
+
 def test_ops_fail_loudly_on_cpu_tensors():
     from generative_recommenders_amd.ops.hstu_attention import delta_hstu_mha, hstu_mha
     from generative_recommenders_amd.ops.jagged_tensors import asynchronous_complete_cumsum, concat_2D_jagged
