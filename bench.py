@@ -201,7 +201,14 @@ def attention_section(args, rank, world, device):
     if bwd is not None:
         step_spread["bwd_ms"] = spread([e[1].elapsed_time(e[2]) for e in ev])
     assert finite(out), "non-finite values in the benchmark outputs"
+    parity = None
+    if getattr(args, "parity_users", 0) and wl in ("M-full", "M-jag", "M-targets", "C4") and rank == 0:
+        try:
+            parity = parity_sample(q, k, v, dout, out, dq, dk, dv, off, nt, N, alpha, n_users=args.parity_users)
+        except Exception as e:  # pragma: no cover -- the headline number must survive a failure of the checker
+            parity = {"error": repr(e)[:300]}
     return dict(
+        parity=parity,
         elapsed=elapsed, users=B, rows=L, total_rows=dp.sum_over_ranks(float(L), device), fwd_ms=fwd_ms, bwd_ms=bwd_ms,
         fwd_gbps=fwd_bytes / fwd_ms / 1e6, bwd_gbps=(bwd_bytes / bwd_ms / 1e6) if bwd_ms else 0.0,
         both_gbps=(fwd_bytes + bwd_bytes) / (fwd_ms + bwd_ms) / 1e6, bwd_bytes=bwd_bytes, fwd_bytes=fwd_bytes,
@@ -250,6 +257,7 @@ def extra_workloads(args, rank, world, device):
         a.max_seq_len, a.heads, a.head_dim, a.users_per_gpu = n, h, over.get("head_dim", d), over.get("users", users)
         a.steps, a.warmup = over.get("steps", args.extra_steps), over.get("warmup", over.get("steps", 24) // 8)   # (sub-millisecond steps: more of them, or the loop is over before the clocks have settled)
         a.sort_by_length = a.workload == "C3"
+        a.parity_users = 0          # (the headline batch carries the oracle check)
         try:
             att = attention_section(a, rank, world, device)
             main, fwd, both = rooflines(att, a.workload)
@@ -286,6 +294,168 @@ def copy_bandwidth(device):
     e1.record()
     torch.cuda.synchronize()
     return 2 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+class Telemetry:
+    """Clocks / power / temperature of this rank's GPU sampled by a background thread while a section runs, so that a slow
+    box is visible in the bench line itself.  Source: the amdgpu sysfs nodes (hwmon freq1 = sclk, freq2 = mclk, power1,
+    temp1..3; no subprocess, ~50 us per sample); when they are not readable, one ``rocm-smi`` call before and after."""
+
+    def __init__(self, device, period=0.02):
+        import glob
+        import threading
+
+        self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
+        self.nodes, self.source = {}, None
+        bus = None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                    continue
+                slot = os.path.basename(os.path.realpath(dev))
+                cards.append((slot, dev))
+            except Exception:
+                continue
+        pick = [c for c in cards if bus and c[0].startswith(bus)] or cards[:1]
+        if pick:
+            dev = pick[0][1]
+            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+            if hw:
+                for key, names in (("sclk_mhz", ("freq1_input",)), ("mclk_mhz", ("freq2_input",)),
+                                   ("power_w", ("power1_average", "power1_input")),
+                                   ("temp_edge_c", ("temp1_input",)), ("temp_junction_c", ("temp2_input",)), ("temp_mem_c", ("temp3_input",))):
+                    for n in names:
+                        f = os.path.join(hw[0], n)
+                        if os.access(f, os.R_OK):
+                            self.nodes[key] = f
+                            break
+            self.source = f"sysfs {pick[0][0]}" + ("" if bus and pick[0][0].startswith(bus) else " (first amdgpu card: PCI id of the torch device not matched)")
+        self._smi = None if self.nodes else self._rocm_smi()
+
+    @staticmethod
+    def _rocm_smi():
+        import subprocess
+
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20).stdout
+            card = next(iter(json.loads(out).values()))
+            return {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "power", "temperature"))}
+        except Exception as e:
+            return {"error": repr(e)[:200]}
+
+    def _read(self):
+        row = {}
+        for key, f in self.nodes.items():
+            try:
+                v = float(open(f).read().strip())
+                row[key] = v / 1e6 if key.endswith("_mhz") or key == "power_w" else v / 1e3
+            except Exception:
+                pass
+        return row
+
+    def __enter__(self):
+        import threading
+
+        if self.nodes:
+            def loop():
+                while not self._stop.is_set():
+                    self.samples.append(self._read())
+                    self._stop.wait(self.period)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+        return False
+
+    def summary(self):
+        if not self.nodes:
+            return {"source": "rocm-smi (sysfs hwmon not readable)", "before": self._smi, "after": self._rocm_smi()}
+        res = {"source": self.source, "samples": len(self.samples), "period_s": self.period}
+        for key in self.nodes:
+            xs = [r[key] for r in self.samples if key in r]
+            if xs:
+                res[key] = {"min": round(min(xs), 1), "mean": round(sum(xs) / len(xs), 1), "max": round(max(xs), 1)}
+        return res
+
+
+def calibration(device):
+    """what THIS box sustains for the two resources the kernels are priced against, from streams that do nothing else
+    (csrc/aux_ops.hip): an MFMA chain without memory traffic (two waves per SIMD, 32x32x16 bf16) and a non-temporal
+    read of 2 GiB; plus the plain device copy torch issues.  The product numbers of two boxes compare through these."""
+    from generative_recommenders_amd.ops import _launch
+
+    res = {}
+    launch, flop = _launch.calib_mfma_stream(device, iters=8192)
+    for _ in range(2):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    tf = flop * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    # 1024 FLOP per clock and SIMD (32x32x16 bf16: 32768 FLOP in 8 passes of 4 clocks): the clock an MFMA-saturated chip holds
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    res["mfma_stream_tflops"] = round(tf, 1)
+    res["mfma_stream_frac_of_2500"] = round(tf / MFMA_PEAK_TFLOPS, 3)
+    res["mfma_stream_effective_mhz"] = round(tf * 1e12 / (n_cu * 4 * 1024) / 1e6, 0)
+    buf = torch.empty(2 << 30, dtype=torch.uint8, device=device)
+    rd = _launch.calib_read_stream(buf)
+    for _ in range(2):
+        rd()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        rd()
+    e1.record()
+    torch.cuda.synchronize()
+    res["read_stream_GBps"] = round(buf.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 0)
+    del buf
+    res["copy_GBps"] = round(copy_bandwidth(device), 0)
+    return res
+
+
+def parity_sample(q, k, v, dout, out, dq, dk, dv, off, nt, N, alpha, n_users=32, seed=77):
+    """``n_users`` randomly chosen users of the batch the timed loop ran on: out, dq, dk, dv as the kernels left them
+    against oracle/hstu_oracle.py (fp64) on the same rows -- relative Frobenius error per tensor.  Runs AFTER the timed
+    region; the oracle is the checker only."""
+    import numpy as np
+
+    from oracle import hstu_oracle as O
+
+    B = off.numel() - 1
+    gen = torch.Generator().manual_seed(seed)
+    users = torch.randperm(B, generator=gen)[:min(n_users, B)].sort().values
+    off_c = off.cpu()
+    rows = torch.cat([torch.arange(int(off_c[u]), int(off_c[u + 1])) for u in users.tolist()]).to(q.device)
+    lens = torch.tensor([int(off_c[u + 1] - off_c[u]) for u in users.tolist()])
+    so = torch.zeros(len(lens) + 1, dtype=torch.int64)
+    so[1:] = torch.cumsum(lens, 0)
+    f = lambda t: t.index_select(0, rows).double().cpu().numpy()
+    nts = None if nt is None else nt.index_select(0, users.to(nt.device)).cpu().numpy()
+    qs, ks, vs, dos = f(q), f(k), f(v), f(dout)
+    ref_o = O.hstu_mha_fwd(N, alpha, qs, ks, vs, so.numpy(), num_targets=nts)
+    ref_q, ref_k, ref_v = O.hstu_mha_bwd(N, alpha, dos, qs, ks, vs, so.numpy(), num_targets=nts)
+    res = {}
+    for name, got, want in (("out", out, ref_o), ("dq", dq, ref_q), ("dk", dk, ref_k), ("dv", dv, ref_v)):
+        g = f(got)
+        res[name] = float(np.linalg.norm(g - want) / max(np.linalg.norm(want), 1e-300))
+    worst = max(res.values())
+    return {"users_checked": int(len(lens)), "rows_checked": int(so[-1]), "rel_fro": {k_: float("%.3e" % v_) for k_, v_ in res.items()},
+            "max_rel_fro": float("%.3e" % worst), "gate_bf16": 3.8e-3, "ok": bool(worst < 3.8e-3),
+            "what": "users drawn at random (seed 77) from the timed batch, outputs of the LAST timed step against oracle/hstu_oracle.py in fp64 "
+                    "(gate = tests/test_attention_gpu.py's bf16 gate; 1.66e-3 of it is the rounding of an exact result to bf16)"}
 
 
 def rccl_section(world, device, nbytes=22 << 20):
@@ -397,9 +567,15 @@ def layer_section(args, rank, world, device):
 
 
 def projection_section(rows, D, device):
-    """MFMA utilisation of the six projection GEMMs of one STU layer at the layer section's shape (hipBLASLt through
-    torch, bf16; the calls ops/hstu_compute.py makes: linear on a K-contiguous weight copy / addmm with the residual, mm for the data gradients, ops/mm.py's slab-split
-    batched GEMM for the weight gradients): TFLOP/s and the fraction of the dense bf16 peak, HIP events around 10 calls each."""
+    """MFMA utilisation of the projections of one STU layer at the layer section's shape, HIP events around 10 calls each:
+    TFLOP/s and the fraction of the dense bf16 peak.  ``uvqk_fwd_fused`` / ``uvqk_fwd_fused_with_normed`` = what the product
+    runs for the forward UVQK projection (and its recompute in backward): the hand-written LayerNorm + GEMM kernel
+    (csrc/hstu_ln_linear.cuh; the layer norm is INSIDE the timed call; also us per call and GB/s of its algorithmic bytes --
+    x in, y out -- against 8 TB/s).  ``uvqk_fwd`` = the hipBLASLt ``linear`` the product falls back to for shapes the fused
+    kernel does not take, kept as the comparator (no layer norm in it).  The other five are the calls ops/hstu_compute.py
+    makes: addmm with the residual, mm for the data gradients, ops/mm.py's slab-split batched GEMM for the weight gradients;
+    ``bias_grad`` = hstu_column_sum (HBM-bound: GB/s)."""
+    from generative_recommenders_amd.ops import _launch
     from generative_recommenders_amd.ops.hstu_compute import _uvqk_dgrad, _uvqk_gemm, _uvqk_prepare
     from generative_recommenders_amd.ops.mm import weight_grad_mm
 
@@ -412,14 +588,24 @@ def projection_section(rows, D, device):
     w_out = torch.randn(3 * D, D, device=device, dtype=dt)
     g_out = torch.randn(rows, D, device=device, dtype=dt)
     w_mul, kmajor = _uvqk_prepare(w_uvqk, dt)      # the K-major copy the product caches per parameter version
-    cases = {
+    ln_w, ln_b = torch.ones(D, device=device, dtype=dt), torch.zeros(D, device=device, dtype=dt)
+    fused_ok = kmajor and _launch.ln_linear_supported(x, 4 * D)
+    cases = {}
+    if fused_ok:
+        cases["uvqk_fwd_fused"] = (lambda: _launch.ln_linear_fwd(x, ln_w, ln_b, 1e-6, w_mul, b_uvqk, want_normed=False), 2.0 * rows * D * 4 * D)
+        cases["uvqk_fwd_fused_with_normed"] = (lambda: _launch.ln_linear_fwd(x, ln_w, ln_b, 1e-6, w_mul, b_uvqk, want_normed=True), 2.0 * rows * D * 4 * D)
+    cases.update({
         "uvqk_fwd": (lambda: _uvqk_gemm(x, w_mul, kmajor, b_uvqk), 2.0 * rows * D * 4 * D),
         "uvqk_dgrad": (lambda: _uvqk_dgrad(g_uvqk, w_mul, kmajor), 2.0 * rows * D * 4 * D),
         "uvqk_wgrad": (lambda: weight_grad_mm(x, g_uvqk), 2.0 * rows * D * 4 * D),
         "out_fwd": (lambda: torch.addmm(x, y3, w_out), 2.0 * rows * 3 * D * D),      # + the residual
         "out_dgrad": (lambda: torch.mm(g_out, w_out.t()), 2.0 * rows * 3 * D * D),
         "out_wgrad": (lambda: weight_grad_mm(y3, g_out), 2.0 * rows * 3 * D * D),
-    }
+    })
+    hbm_bytes = {"uvqk_fwd_fused": rows * (D + 4 * D) * 2.0, "uvqk_fwd_fused_with_normed": rows * (2 * D + 4 * D) * 2.0,
+                 "bias_grad": rows * 4 * D * 2.0}
+    if _launch.column_sum_supported(g_uvqk):
+        cases["bias_grad"] = (lambda: _launch.column_sum(g_uvqk), 0.0)
     res = {}
     for name, (fn, flops) in cases.items():
         for _ in range(3):
@@ -430,8 +616,16 @@ def projection_section(rows, D, device):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        tf = flops * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12
-        res[name] = {"tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 3)}
+        us = e0.elapsed_time(e1) * 1e3 / 10
+        tf = flops / (us * 1e-6) / 1e12
+        res[name] = {"tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 3), "us": round(us, 1)}
+        if name in hbm_bytes:
+            gbps = hbm_bytes[name] / (us * 1e-6) / 1e9
+            res[name].update(algorithmic_GBps=round(gbps, 0), hbm_frac=round(gbps / HBM_PEAK_GBPS, 3))
+        if name.startswith("uvqk_fwd_fused"):
+            res[name]["kernel"] = "hstu_ln_linear_fwd_kernel (LayerNorm inside; what the product runs)"
+        if name == "uvqk_fwd":
+            res[name]["kernel"] = "hipBLASLt linear (comparator: the product runs uvqk_fwd_fused at this shape)" if fused_ok else "hipBLASLt linear"
     return res
 
 
@@ -630,7 +824,12 @@ def run(args):
     device = torch.device("cuda", dev_index)
     _lib.lib()
 
-    att = attention_section(args, rank, world, device)
+    telem = Telemetry(device) if rank == 0 else None
+    if telem is not None:
+        with telem:
+            att = attention_section(args, rank, world, device)
+    else:
+        att = attention_section(args, rank, world, device)
     value = world * att["users"] * args.steps / att["elapsed"]
     N, H, d = args.max_seq_len, args.heads, args.head_dim
     what = "fwd" if att["fwd_only"] else "fwd+bwd"
@@ -655,17 +854,25 @@ def run(args):
         "device_ms_per_step": att["device_ms_per_step"], "step_spread": att["step_spread"],
     }
     res["roofline"], res["roofline_fwd"], res["roofline_fwd_bwd"] = rooflines(att, args.workload)
-    res["parity_at_this_size"] = ("by invariance only: batch-composition bit-exactness, delta == tail of full, linearity in V "
-                                  "(tests/test_attention_gpu.py); the reference-minted vectors at this head shape are "
-                                  "tests/golden/metric_shapes.npz (N = 200, 4 x 128)")
+    res["parity_at_this_size"] = att["parity"] if att.get("parity") else (
+        "by invariance only: batch-composition bit-exactness, delta == tail of full, linearity in V "
+        "(tests/test_attention_gpu.py); the reference-minted vectors at this head shape are "
+        "tests/golden/metric_shapes.npz (N = 200, 4 x 128)")
+    if telem is not None:
+        res["telemetry"] = {"headline": telem.summary()}
     attach_traffic(res, args, att)
     if args.workload == "M-full" and not args.no_extra:
         res["extra_workloads"] = extra_workloads(args, rank, world, device)
     if rank == 0:
         try:
-            res["measured_copy_GBps"] = copy_bandwidth(device)
+            res["calibration"] = calibration(device)
+            res["measured_copy_GBps"] = res["calibration"]["copy_GBps"]
+            c = res["calibration"]
+            # one-number box normalisers: the attention step against what this box's read stream would need for the same
+            # algorithmic bytes, and (layer section below) the fused projection against this box's MFMA stream
+            c["attn_fwd_bwd_bytes_over_read_stream"] = round(res["roofline_fwd_bwd"]["achieved"] / c["read_stream_GBps"], 3)
         except Exception as e:  # pragma: no cover
-            res["measured_copy_GBps"] = f"error: {e}"
+            res["calibration"] = {"error": repr(e)[:300]}
     if world > 1:
         try:
             res["rccl"] = rccl_section(world, device)
@@ -674,7 +881,16 @@ def run(args):
             res["rccl"] = {"error": repr(e)[:300]}
     if not args.no_layer:
         try:
-            res["layer"] = layer_section(args, rank, world, device)
+            telem_l = Telemetry(device) if rank == 0 else None
+            if telem_l is not None:
+                with telem_l:
+                    res["layer"] = layer_section(args, rank, world, device)
+                res.setdefault("telemetry", {})["layer"] = telem_l.summary()
+            else:
+                res["layer"] = layer_section(args, rank, world, device)
+            fused = res["layer"].get("projections", {}).get("uvqk_fwd_fused")
+            if rank == 0 and fused and isinstance(res.get("calibration"), dict) and "mfma_stream_tflops" in res["calibration"]:
+                res["calibration"]["uvqk_fwd_fused_over_mfma_stream"] = round(fused["tflops"] / res["calibration"]["mfma_stream_tflops"], 3)
         except Exception as e:  # the headline number must survive a failure of the secondary section
             res["layer"] = {"error": repr(e)[:300]}
     if rank == 0 and cpu_res is not None:
@@ -717,6 +933,7 @@ def main():
                     help="let PyTorch's TunableOp pick the hipBLASLt / rocBLAS solution of the layer section's six GEMM shapes during its "
                          "warm-up (~20 s; measured 15.1 -> 14.5 ms per step, profiles/r03_layer_tunableop.txt); off by default")
     ap.add_argument("--extra-steps", type=int, default=8)
+    ap.add_argument("--parity-users", type=int, default=32, help="users of the timed batch checked against the oracle after the timed loop (0: off)")
     ap.add_argument("--cpu-users", type=int, default=128)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--sort-by-length", type=int, default=None, help="1: heavy-first workgroup order (default: on for C3)")

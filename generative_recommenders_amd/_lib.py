@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime ou
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSTU_HIP_LIBRARY overrides the in-tree build (A/B measurements of kernel variants, packaged installs)
 LIB_PATH = os.environ.get("HSTU_HIP_LIBRARY") or os.path.join(_HERE, "libhstu_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
 HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
@@ -61,6 +61,13 @@ class HstuAttnBwdParams(C.Structure):
     ]
 
 
+class HstuCastItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("numel", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("transpose", C.c_int32)]
+
+
+CAST_MAX_ITEMS = 8
+
 _vp, _i32, _i64, _f32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_int
 _fp = C.POINTER(C.c_float)
 
@@ -101,6 +108,11 @@ SIGNATURES = {
     "hstu_embedding_grad_workspace_bytes": (_int, [_i64, _i32, _vp]),
     "hstu_embedding_grad": (_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _int, _vp]),
     "hstu_jagged_write_tail": (_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _int, _vp]),
+    "hstu_cast_params": (_int, [C.POINTER(HstuCastItem), _i32, _int, _vp]),
+    "hstu_column_sum_workspace_bytes": (C.c_size_t, [_i64, _i32]),
+    "hstu_column_sum": (_int, [_vp, _i64, _i64, _i32, _vp, _vp, _int, _vp]),
+    "hstu_calib_mfma_stream": (_int, [_i32, _vp, C.POINTER(C.c_double), _vp]),
+    "hstu_calib_read_stream": (_int, [_vp, C.c_size_t, _vp, _vp]),
     "hstu_sampled_softmax_fwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _i32,
                                         _i32, _f32, _vp, _vp, _int, _vp]),
     "hstu_sampled_softmax_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _i32,

@@ -33,21 +33,6 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 
-// head dim 128 of the folded shapes: the wide schedule (four waves, one per SIMD, 512 registers each).  Round 4's structural
-// experiment: correct (same tests as the folded kernel) and measured SLOWER (3.28-3.85 ms against 2.99-3.07 ms on the metric
-// shape: docs/EXPERIMENTS.md Part R4), so it is opt-in: HSTU_BWD_WIDE=1.
-bool attn_bwd_wide_applicable(const HstuAttnBwdParams& bp) {
-  static const bool enabled = [] { const char* e = getenv("HSTU_BWD_WIDE"); return e && e[0] == '1'; }();
-  if (!enabled || !attn_bwd_fold_applicable(bp) || bp.fwd.dqk != 128 || bp.fwd.dv != 128) return false;
-  // its LDS-DMA source addresses are a scalar base + a 32-bit offset (24-bit multiply): row strides below 16 MiB, a user's rows
-  // within 4 GiB of its first row; its register -> memory stores go through buffer descriptors of at most 2 GiB per tile
-  const HstuAttnParams& p = bp.fwd;
-  const int64_t rows = 32 * ((p.max_seq_len + 31) / 32);
-  for (int64_t rs : {p.q_row_stride, p.k_row_stride, p.v_row_stride, bp.do_row_stride, bp.dq_row_stride, bp.dk_row_stride, bp.dv_row_stride})
-    if (rs * 2 >= (1 << 24) || rows * rs * 2 >= (1LL << 31)) return false;
-  return true;
-}
-
 bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {
   static const bool enabled = [] { const char* e = getenv("HSTU_SOLO"); return !(e && e[0] == '0'); }();
   if (!enabled || p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.delta_q != 0) return false;
@@ -130,7 +115,6 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   if (p.pos_w && a != v) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "relative-bias attention is instantiated for dqk == dv"); }
   if (attn_solo_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_kernel<%s>", bwd ? "bwd" : "fwd", dt);
   else if (attn_solo_bias_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_bias_kernel<%s>", bwd ? "bwd" : "fwd", dt);
-  else if (bwd && attn_bwd_wide_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_wide_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
   else if (bwd && attn_bwd_fold_bias_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_bias_kernel<%s,64>", dt);

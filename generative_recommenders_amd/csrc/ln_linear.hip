@@ -1,7 +1,7 @@
 // C entry points of the fused LayerNorm + projection kernel (hstu_ln_linear.cuh).
 #include <stdlib.h>
 
-#include "hstu_ln_linear2.cuh"
+#include "hstu_ln_linear.cuh"
 
 using namespace hstu;
 
@@ -32,10 +32,6 @@ int hstu_ln_linear_fwd(const void* x, int64_t ldx, const void* ln_weight, const 
   g.units = ((rows + kLnlBlockRows - 1) / kLnlBlockRows) * g.n_tiles;
   g.eps = eps;
   hipStream_t st = (hipStream_t)stream;
-  // HSTU_LNL_SPLIT=1: two four-wave workgroups per CU (hstu_ln_linear2.cuh) where that arrangement applies
-  static const bool split = [] { const char* e = getenv("HSTU_LNL_SPLIT"); return e && e[0] == '1'; }();
-  if (split && !normed && n <= kLn2MaxN)
-    return dtype == HSTU_DTYPE_BF16 ? launch_ln_linear2<bf16_t>(g, st) : launch_ln_linear2<f16_t>(g, st);
   return dtype == HSTU_DTYPE_BF16 ? launch_ln_linear<bf16_t>(g, st) : launch_ln_linear<f16_t>(g, st);
 }
 

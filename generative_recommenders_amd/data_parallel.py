@@ -116,11 +116,13 @@ class GradientAllReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True,
-                 buckets: Optional[Sequence[Iterable[torch.nn.Parameter]]] = None, overlap: bool = False):
+                 buckets: Optional[Sequence[Iterable[torch.nn.Parameter]]] = None, overlap: bool = False,
+                 check_every: int = 0):
         """``buckets``: explicit parameter groups (e.g. one per layer) instead of the byte-size split of ``params``.
         ``overlap``: launch a bucket's all-reduce from inside backward, as soon as its last gradient has been
         accumulated (hooks); ``reduce()`` then only waits.  The reference's DDP does the same (train.py:269)."""
         self.average = average
+        self.check_every = int(check_every)     # overlap mode: every N-th reduce() compares the late-bucket sets across ranks (0: never)
         self.buckets: List[List[torch.nn.Parameter]] = []
         if buckets is not None:
             # a bucket is ONE flat buffer: parameters of different dtypes (or devices) of a group get buckets of their own,
@@ -232,26 +234,30 @@ class GradientAllReducer:
             # Collectives pair up across ranks by ISSUE ORDER.  The hooks launch a bucket when its last gradient arrives, i.e. in
             # backward order, identical on every rank as long as every parameter gets a gradient everywhere.  A bucket that is
             # incomplete on this rank (parameters unused in this step) is reduced here -- zeros for the missing gradients --
-            # in bucket order AFTER the hook-launched ones; ranks on which the same bucket was complete launched it from a
-            # hook, which would pair different buffers: so the set of incomplete buckets must be the same on all ranks (the
-            # model's parameter usage may not depend on the rank's data).  That precondition is checked, not assumed: one
-            # tiny all-reduce of the bucket-state bitmap per step, only in steps that have an incomplete bucket anywhere.
+            # in bucket order AFTER the hook-launched ones; a rank on which the same bucket was complete launched it from a
+            # hook already, and the two would pair different buffers.  PRECONDITION (documented, not detectable in time): the
+            # set of parameters that receive a gradient in a step is the same on every rank -- the model's parameter usage
+            # may not depend on a rank's data (otherwise: overlap=False).  No per-step state exchange, no host sync: by the
+            # time a mismatch could be seen, the mispaired collectives have been issued.  ``check_every = N > 0`` is a
+            # debugging aid for runs under a collective timeout: every N-th call all ranks exchange their late-bucket bitmap
+            # (one MAX all-reduce of the bitmap and its complement) and ALL of them raise when the bitmaps differ.
             late = [bi for bi, w in enumerate(self._work) if w is None and self._pending[bi] != 0]
             for bi, work in enumerate(self._work):
                 if work is not None:
                     work.wait()
                     if self.average:
                         self._flat[bi].div_(world)
-            if world > 1 and self._sync:
+            self._calls = getattr(self, "_calls", 0) + 1
+            if world > 1 and self._sync and self.check_every > 0 and self._calls % self.check_every == 0:
                 ref = self.buckets[0][0]
-                state = torch.zeros(len(self.buckets) + 1, dtype=torch.int32, device=ref.device)
-                for bi in late:
-                    state[bi] = 1
-                state[-1] = 1 if late else 0
-                # (every rank takes part: a rank without late buckets cannot know whether another one has some)
-                mx = state.clone()
-                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                if int(mx[-1]) and not torch.equal(mx[:-1], state[:-1]):
+                nb = len(self.buckets)
+                state = torch.zeros(2 * nb, dtype=torch.int32, device=ref.device)
+                for bi in range(nb):
+                    state[bi] = 1 if bi in late else 0
+                    state[nb + bi] = 1 - int(state[bi])
+                dist.all_reduce(state, op=dist.ReduceOp.MAX)
+                # a bucket late on some ranks and not on others shows up as 1 in BOTH halves -- on every rank
+                if bool((state[:nb] + state[nb:] > 1).any()):
                     raise RuntimeError("GradientAllReducer(overlap=True): the buckets with parameters that received no gradient differ "
                                        "between ranks -- their collectives would pair different buffers.  Parameter usage must not "
                                        "depend on a rank's data (or use overlap=False).")

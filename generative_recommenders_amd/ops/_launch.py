@@ -492,6 +492,86 @@ def silu_bwd(dout: torch.Tensor, x: torch.Tensor, din: Optional[torch.Tensor] = 
     return din
 
 
+# ----------------------------------------------------------------------------- glue around the projections (ABI v10)
+def cast_params(tensors, dtype, transpose_index: Optional[int] = None):
+    """fp32 CUDA parameters -> ``dtype`` (bf16 / fp16) copies in ONE launch (hstu_cast_params); the tensor at
+    ``transpose_index`` (2-D) comes back as its transposed, contiguous (cols, rows) copy.  All copies are views of one flat
+    buffer (each starts 16-byte aligned)."""
+    n = len(tensors)
+    torch._assert(0 < n <= L.CAST_MAX_ITEMS, "cast_params: 1..8 tensors")
+    dev = tensors[0].device
+    srcs = []
+    sizes = []
+    for t in tensors:
+        L.require_gpu_tensor(t, "parameter")
+        torch._assert(t.dtype == torch.float32 and t.device == dev, "cast_params: fp32 tensors on one device")
+        srcs.append(t.detach().contiguous())
+        sizes.append((t.numel() + 7) // 8 * 8)
+    flat = torch.empty(sum(sizes), dtype=dtype, device=dev)
+    items = (L.HstuCastItem * n)()
+    outs = []
+    pos = 0
+    for i, (t, sz) in enumerate(zip(srcs, sizes)):
+        dst = flat[pos : pos + t.numel()]
+        pos += sz
+        items[i].src, items[i].dst, items[i].numel = t.data_ptr(), dst.data_ptr(), t.numel()
+        if i == transpose_index:
+            torch._assert(t.dim() == 2, "cast_params: the transposed item must be 2-D")
+            items[i].rows, items[i].cols, items[i].transpose = t.shape[0], t.shape[1], 1
+            outs.append(dst.view(t.shape[1], t.shape[0]))
+        else:
+            items[i].rows = items[i].cols = items[i].transpose = 0
+            outs.append(dst.view(t.shape))
+    with torch.cuda.device(dev):
+        L.check(L.lib().hstu_cast_params(items, n, L.torch_dtype_code(dtype), L.current_stream_ptr(dev)))
+    return outs
+
+
+def column_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 column sums of a 2-D bf16 / fp16 tensor with contiguous rows (hstu_column_sum: fixed summation order)"""
+    L.require_gpu_tensor(x, "x")
+    torch._assert(x.dim() == 2 and x.stride(1) == 1, "column_sum: a 2-D tensor with contiguous rows")
+    rows, cols = x.shape
+    if out is None:
+        out = _f32(cols, x.device)
+    if workspace is None:
+        workspace = torch.empty(max(16, L.lib().hstu_column_sum_workspace_bytes(rows, cols)), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_column_sum(x.data_ptr(), x.stride(0) if rows > 1 else max(cols, x.stride(0)), rows, cols, out.data_ptr(),
+                                        workspace.data_ptr(), L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
+    return out
+
+
+def column_sum_supported(x: torch.Tensor) -> bool:
+    return bool(x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.stride(1) == 1 and
+                x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def calib_mfma_stream(device, iters: int = 4096):
+    """(launch, flop per launch): the MFMA calibration stream of bench.py (hstu_calib_mfma_stream)"""
+    sink = _f32(4, device)
+    flops = C.c_double(0.0)
+
+    def launch():
+        with torch.cuda.device(device):
+            L.check(L.lib().hstu_calib_mfma_stream(int(iters), sink.data_ptr(), C.byref(flops), L.current_stream_ptr(device)))
+
+    launch()
+    return launch, flops.value
+
+
+def calib_read_stream(src: torch.Tensor):
+    """launch(): one non-temporal read of ``src`` (hstu_calib_read_stream)"""
+    sink = _f32(4, src.device)
+    nbytes = src.numel() * src.element_size()
+
+    def launch():
+        with torch.cuda.device(src.device):
+            L.check(L.lib().hstu_calib_read_stream(src.data_ptr(), nbytes, sink.data_ptr(), L.current_stream_ptr(src.device)))
+
+    return launch
+
+
 # ----------------------------------------------------------------------------- row L2 normalisation
 def l2_norm_fwd(x: torch.Tensor, eps: float) -> torch.Tensor:
     L.require_gpu_tensor(x, "x")

@@ -69,8 +69,8 @@ class _LnUvqkFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, eps):
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
-        nw, nb, beta = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_bias))
-        w, kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
+        (nw, nb, w, beta), kmajor = _prepare_params((norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2,
+                                                    any(ctx.needs_input_grad[1:5]))
         uvqk, _, mean, rstd = _ln_uvqk(x, nw, nb, eps, w, kmajor, beta, want_normed=False)
         ctx.save_for_backward(x, nw, nb, mean, rstd, w)
         ctx.kmajor, ctx.eps = kmajor, eps
@@ -82,11 +82,11 @@ class _LnUvqkFunction(torch.autograd.Function):
         duvqk = duvqk.contiguous()
         normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, ctx.eps)
         dt = ctx.param_dtypes
+        bias_grad = _BiasGrad(duvqk, dt[3])
         d_normed = _uvqk_dgrad(duvqk, w, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
-        dbeta = duvqk.sum(dim=0, dtype=torch.float32 if dt[3] == torch.float32 else None)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
-        return dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, dbeta.to(dt[3]), None
+        return dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), None
 
 
 class _SiluFunction(torch.autograd.Function):
@@ -116,12 +116,23 @@ _UVQK_LINEAR = os.environ.get("HSTU_UVQK_LINEAR", "1") != "0"
 
 _KMAJOR_CACHE: dict = {}      # id(parameter) -> (weak reference, (version, dtype, data_ptr), copy); tensors compare element-wise,
                                # so they cannot key a (weak) dictionary themselves
+_PARAM_CACHE: dict = {}       # ids of a layer's parameters -> (weak references, key, casted copies): inference only
+
+
+def invalidate_parameter_caches() -> None:
+    """Drop every cached low-precision copy of a parameter.  The caches serve calls that do NOT track gradients (inference:
+    24 layers x 7 parameters would otherwise be re-cast for every microbatch) and are keyed on the parameters' version
+    counters, which an optimizer step, ``load_state_dict`` or any in-place op on the parameter bumps.  Writing through
+    ``parameter.data`` (``p.data.mul_(..)``, weight EMA swaps by ``.data`` assignment of the same storage) does NOT bump
+    the counter: call this afterwards.  Calls that track gradients (training) never read the caches."""
+    _KMAJOR_CACHE.clear()
+    _PARAM_CACHE.clear()
 
 
 def _kmajor(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """The (in, out) projection weight as a K-contiguous (out, in) copy in the activations' dtype: ONE transposing, casting
-    pass, cached per parameter until the parameter changes (its version counter: an optimizer step, a load_state_dict) --
-    forward, the recompute in backward and every inference call of an unchanged weight share one copy."""
+    pass, cached per parameter until the parameter changes (its version counter: an optimizer step, a load_state_dict).
+    Only calls that do not track gradients come here (see invalidate_parameter_caches for the ``.data`` caveat)."""
     wid = id(weight)
     key = (weight._version, dtype, weight.data_ptr())
     hit = _KMAJOR_CACHE.get(wid)
@@ -131,6 +142,86 @@ def _kmajor(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     wt.copy_(weight.detach().t())
     _KMAJOR_CACHE[wid] = (weakref.ref(weight, lambda _r, wid=wid: _KMAJOR_CACHE.pop(wid, None)), key, wt)
     return wt
+
+
+def _cast_fresh(params, dtype, kmajor_index):
+    """the parameters in ``dtype``, cast NOW: every fp32 CUDA parameter in one launch (hstu_cast_params; the one at
+    ``kmajor_index`` as its K-contiguous transpose), anything else by torch"""
+    outs = [None] * len(params)
+    batch = [i for i, t in enumerate(params)
+             if t.is_cuda and t.dtype == torch.float32 and dtype in (torch.bfloat16, torch.float16) and t.numel() > 0]
+    if len(batch) >= 2 or (kmajor_index is not None and kmajor_index in batch):
+        res = _launch.cast_params([params[i] for i in batch], dtype,
+                                  transpose_index=batch.index(kmajor_index) if kmajor_index in batch else None)
+        for i, r in zip(batch, res):
+            outs[i] = r
+    for i, t in enumerate(params):
+        if outs[i] is None:
+            if i == kmajor_index:
+                outs[i] = torch.empty((t.shape[1], t.shape[0]), dtype=dtype, device=t.device)
+                outs[i].copy_(t.detach().t())
+            else:
+                outs[i] = _cast(t, dtype)
+    return outs
+
+
+def _prepare_params(params, dtype, kmajor_index, tracked):
+    """(copies, kmajor): a node's parameters in the activations' dtype, the UVQK weight (``kmajor_index``) as its K-contiguous
+    copy where hipBLASLt / the fused kernel want it.  ``tracked`` (the call records a graph: training): cast now, every
+    time -- a cache keyed on the version counter would miss writes through ``.data`` (legacy optimizers, EMA swaps) and
+    multiply by a stale weight silently; one launch per node covers all of them.  Otherwise the copies are cached per
+    parameter set until a version counter moves (invalidate_parameter_caches)."""
+    want_kmajor = kmajor_index is not None and _UVQK_LINEAR and params[kmajor_index].is_cuda
+    kidx = kmajor_index if want_kmajor else None
+    if tracked:
+        return _cast_fresh(params, dtype, kidx), want_kmajor
+    ids = tuple(id(t) for t in params)
+    key = tuple((t._version, t.data_ptr(), t.dtype) for t in params) + (dtype, want_kmajor)
+    hit = _PARAM_CACHE.get(ids)
+    if hit is not None and hit[1] == key and all(r() is t for r, t in zip(hit[0], params)):
+        return hit[2], want_kmajor
+    outs = _cast_fresh(params, dtype, kidx)
+    refs = tuple(weakref.ref(t, lambda _r, ids=ids: _PARAM_CACHE.pop(ids, None)) for t in params)
+    _PARAM_CACHE[ids] = (refs, key, outs)
+    return outs, want_kmajor
+
+
+# d uvqk_beta = the column sums of d uvqk (triton_addmm.py:309): one HBM-bound read of (rows, 2048) 16-bit values
+# (hstu_column_sum, fixed summation order).  HSTU_DBETA_STREAM=1 (default) launches it on a side stream so that it runs
+# UNDER the two MFMA-bound GEMMs that read d uvqk next instead of in front of them; 0 keeps it on the caller's stream.
+_DBETA_STREAM = os.environ.get("HSTU_DBETA_STREAM", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+class _BiasGrad:
+    """starts the column sums of ``duvqk`` (fp32); ``result()`` joins them into the caller's stream"""
+
+    def __init__(self, duvqk: torch.Tensor, out_dtype: torch.dtype):
+        self.side = None
+        if not _launch.column_sum_supported(duvqk):
+            self.out = duvqk.sum(dim=0, dtype=torch.float32 if out_dtype == torch.float32 else None)
+            return
+        if not _DBETA_STREAM:
+            self.out = _launch.column_sum(duvqk)
+            return
+        dev = duvqk.device
+        rows, cols = duvqk.shape
+        # allocated on the caller's stream (so that the caching allocator hands them back to it), written on the side stream
+        self.out = torch.empty(cols, dtype=torch.float32, device=dev)
+        ws = torch.empty(max(16, _launch.L.lib().hstu_column_sum_workspace_bytes(rows, cols)), dtype=torch.uint8, device=dev)
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            _launch.column_sum(duvqk, out=self.out, workspace=ws)
+        self.side, self._ws = side, ws
+
+    def result(self) -> torch.Tensor:
+        if self.side is not None:
+            torch.cuda.current_stream(self.out.device).wait_stream(self.side)   # (duvqk and the workspace outlive this point)
+            self.side = None
+        return self.out
 
 
 def _uvqk_prepare(weight: torch.Tensor, dtype: torch.dtype):
@@ -216,7 +307,8 @@ class _ComputeOutputFunction(torch.autograd.Function):
         # _ln_mul_dropout_fwd does (triton_hstu_linear.py:101-120); the mask is never stored -- the backward kernel and the
         # recompute of y regenerate it from the seed
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, output_weight.dtype)
-        norm_weight, norm_bias, output_weight = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, output_weight))
+        (norm_weight, norm_bias, output_weight), _ = _prepare_params((norm_weight, norm_bias, output_weight), x.dtype, None,
+                                                                      any(ctx.needs_input_grad[3:6]))
         y, mean, rstd = _launch.norm_mul_fwd(attn, u, norm_weight, norm_bias, eps, num_heads, linear_dim, group_norm,
                                              concat_ux, dropout_ratio, seed)
         out = torch.addmm(x, y, output_weight)
@@ -280,8 +372,8 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                 num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
                 recompute_uvqk, recompute_normed_x, user_order=None):
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
-        norm_weight, norm_bias, uvqk_bias = (_cast(t, x.dtype) for t in (norm_weight, norm_bias, uvqk_bias))
-        uvqk_weight, ctx.kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
+        (norm_weight, norm_bias, uvqk_weight, uvqk_bias), ctx.kmajor = _prepare_params(
+            (norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2, any(ctx.needs_input_grad[1:5]))
         uvqk, normed_x, mean, rstd = _ln_uvqk(x, norm_weight, norm_bias, norm_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
                                               want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
@@ -333,11 +425,11 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                          dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         _launch.silu_bwd(du, uvqk[:, :hv], din=duvqk[:, :hv])
         nw_dtype, nb_dtype, w_dtype, beta_dtype = ctx.param_dtypes
+        bias_grad = _BiasGrad(duvqk, beta_dtype)
         d_normed = _uvqk_dgrad(duvqk, W, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=w_dtype)
-        dbeta = duvqk.sum(dim=0, dtype=torch.float32 if beta_dtype == torch.float32 else None)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
-        return (dx, dnw.to(nw_dtype), dnb.to(nb_dtype), dW, dbeta.to(beta_dtype), None, None, None, None, None, None,
+        return (dx, dnw.to(nw_dtype), dnb.to(nb_dtype), dW, bias_grad.result().to(beta_dtype), None, None, None, None, None, None,
                 None, None, None, None, None, None, None)
 
 
@@ -361,9 +453,8 @@ class _STULayerFunction(torch.autograd.Function):
                 in_eps, out_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
                 recompute_uvqk, recompute_normed_x, recompute_y, concat_ux, group_norm, dropout_ratio, seed, user_order):
         ctx.param_dtypes = tuple(t.dtype for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
-        in_nw, in_nb, uvqk_bias, out_nw, out_nb, output_weight = (
-            _cast(t, x.dtype) for t in (in_nw, in_nb, uvqk_bias, out_nw, out_nb, output_weight))
-        uvqk_weight, ctx.kmajor = _uvqk_prepare(uvqk_weight, x.dtype)
+        (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight), ctx.kmajor = _prepare_params(
+            (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight), x.dtype, 2, any(ctx.needs_input_grad[1:8]))
         uvqk, normed_x, mean, rstd = _ln_uvqk(x, in_nw, in_nb, in_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
                                               want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
@@ -429,11 +520,11 @@ class _STULayerFunction(torch.autograd.Function):
         _launch.attn_bwd(dattn.view(-1, H, Hd), q, k, v, seq_offsets, num_targets, N, alpha, 1.0 / N, w, c, 0,
                          dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         # ---- projections and the input norm (+ the residual's gradient, inside the kernel)
+        bias_grad = _BiasGrad(duvqk, dt[3])
         d_normed = _uvqk_dgrad(duvqk, W, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
-        dbeta = duvqk.sum(dim=0, dtype=torch.float32 if dt[3] == torch.float32 else None)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd, dresidual=dout)
-        return (dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, dbeta.to(dt[3]), donw.to(dt[4]), donb.to(dt[5]), dWo) + (None,) * 19
+        return (dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), donw.to(dt[4]), donb.to(dt[5]), dWo) + (None,) * 19
 
 
 def hstu_fused_layer_applicable(x: torch.Tensor, attn_dim: int, hidden_dim: int) -> bool:

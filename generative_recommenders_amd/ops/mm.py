@@ -55,8 +55,34 @@ def weight_grad_mm(x: torch.Tensor, dy: torch.Tensor, out_dtype: Optional[torch.
         return torch.mm(x.t(), dy).to(out_dtype)
     slab = (L // S) // 64 * 64
     main = slab * S
-    part = _bmm_f32(x[:main].view(S, slab, K).transpose(1, 2), dy[:main].view(S, slab, N))
+    xs, dys = x[:main].view(S, slab, K).transpose(1, 2), dy[:main].view(S, slab, N)
+    if main < L and _tail_slab_ok(x):
+        # the rows behind the last whole slab: one more fp32 partial next to the slabs', summed with them (no ``.float()`` /
+        # ``+=`` passes over the (K, N) result: three tiny kernels per weight gradient less)
+        part = torch.empty((S + 1, K, N), dtype=torch.float32, device=x.device)
+        torch.bmm(xs, dys, out_dtype=torch.float32, out=part[:S])
+        torch.mm(x[main:].t(), dy[main:], out_dtype=torch.float32, out=part[S])
+        return part.sum(dim=0).to(out_dtype)
+    part = _bmm_f32(xs, dys)
     out = part.sum(dim=0)
     if main < L:
         out += torch.mm(x[main:].t(), dy[main:]).float()
     return out.to(out_dtype)
+
+
+_tail_ok = None
+
+
+def _tail_slab_ok(x: torch.Tensor) -> bool:
+    """does this torch build take ``out_dtype`` together with ``out=`` for mm / bmm (probed once on tiny operands)"""
+    global _tail_ok
+    if _tail_ok is None:
+        try:
+            a = torch.ones(2, 16, 8, dtype=x.dtype, device=x.device)
+            o = torch.empty(3, 8, 8, dtype=torch.float32, device=x.device)
+            torch.bmm(a.transpose(1, 2), a, out_dtype=torch.float32, out=o[:2])
+            torch.mm(a[0].t(), a[0], out_dtype=torch.float32, out=o[2])
+            _tail_ok = bool((o == 16.0).all())
+        except (TypeError, RuntimeError, NotImplementedError):
+            _tail_ok = False
+    return _tail_ok

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 9
+#define HSTU_ABI_VERSION 10
 
 enum {
   HSTU_OK = 0,
@@ -366,6 +366,34 @@ int hstu_sampled_softmax_bwd(const void* q, int64_t q_row_stride, const void* po
                              int32_t dim, float temperature, int32_t pos_l2_norm, int32_t table_l2_norm, float eps,
                              const float* lse, const float* grad_row_loss, void* dq, int64_t dq_row_stride, void* dpos_emb,
                              int64_t dpos_row_stride, float* dtable, int dtype, void* stream);
+
+/* ---- ABI v10: the glue around the projections of an STU layer ---------------------------------------------
+ * hstu_cast_params: up to HSTU_CAST_MAX_ITEMS fp32 tensors -> bf16 / fp16 in ONE launch; an item with transpose != 0 is a
+ * (rows, cols) row-major matrix written as its (cols, rows) transpose (the UVQK weight's K-contiguous copy).  Replaces the
+ * per-parameter ``.to(x.dtype)`` casts the reference issues in front of every projection (ops/hstu_compute.py:62-72,
+ * ops/triton/triton_hstu_linear.py:1160-1170; ops/triton/triton_hstu_preprocess_and_attention.py:60-75). */
+#define HSTU_CAST_MAX_ITEMS 8
+typedef struct HstuCastItem {
+  const float* src;
+  void* dst;
+  int64_t numel;
+  int32_t rows, cols;     /* only read when transpose != 0: rows * cols == numel */
+  int32_t transpose;
+} HstuCastItem;
+int hstu_cast_params(const HstuCastItem* items, int32_t n_items, int dst_dtype, void* stream);
+/* out[c] = sum over r < rows of x[r * ldx + c] (fp32, fixed summation order: bit-identical run to run) for a bf16 / fp16
+ * matrix -- the bias gradient of a projection (ops/triton/triton_addmm.py:309 ``torch.sum(dz, dim=0)``; d uvqk_beta in
+ * ops/triton/triton_hstu_preprocess_and_attention.py:122-293).  cols and ldx multiples of 8, x 16-byte aligned;
+ * `workspace`: hstu_column_sum_workspace_bytes(rows, cols) bytes of device memory, 16-byte aligned. */
+size_t hstu_column_sum_workspace_bytes(int64_t rows, int32_t cols);
+int hstu_column_sum(const void* x, int64_t ldx, int64_t rows, int32_t cols, float* out, void* workspace, int dtype,
+                    void* stream);
+/* Calibration streams for bench.py (no reference counterpart; measurement only): `iters` x 16 independent 32x32x16 bf16
+ * MFMAs per wave, two waves per SIMD on every CU, no memory traffic (*flops = the FLOP the launch performs), and a
+ * non-temporal 16-byte-per-lane read of `bytes` bytes without arithmetic.  What this box sustains for the two resources the
+ * product kernels are priced against, measured in the same process as they are. */
+int hstu_calib_mfma_stream(int32_t iters, float* sink, double* flops, void* stream);
+int hstu_calib_read_stream(const void* src, size_t bytes, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,7 @@ def _worker_overlap(rank, world, port, out_dir):
     mk = lambda: torch.nn.Sequential(*[torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh()) for _ in range(3)])
     torch.manual_seed(0)
     model = mk()
-    red = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in model], overlap=True, average=False)
+    red = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in model], overlap=True, average=False, check_every=1)
     assert len(red.buckets) == 3
     lengths = torch.tensor([5, 1, 9, 3, 7, 2, 8, 4])
     mine = dp.shard_users(lengths, rank, world)
@@ -125,7 +125,7 @@ def _worker_mixed(rank, world, port, out_dir):
     b = torch.nn.Parameter(torch.randn(3, 5).to(torch.bfloat16))
     c = torch.nn.Parameter(torch.randn(5))
     unused = torch.nn.Parameter(torch.randn(2))
-    red = dp.GradientAllReducer(None, buckets=[[a, b, c], [unused, torch.nn.Parameter(torch.randn(2))]], overlap=True, average=False)
+    red = dp.GradientAllReducer(None, buckets=[[a, b, c], [unused, torch.nn.Parameter(torch.randn(2))]], overlap=True, average=False, check_every=1)
     assert [len(bk) for bk in red.buckets] == [2, 1, 2] and red.buckets[1][0] is b
     used2 = red.buckets[2][1]
     x = torch.full((2, 4), float(rank + 1))

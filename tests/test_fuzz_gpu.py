@@ -107,24 +107,3 @@ def test_fuzz_ln_linear(i):
     xs = f(x)
     np.testing.assert_allclose(mean.cpu().numpy(), xs.mean(axis=1), rtol=5e-6, atol=5e-6 * (1 + shift))
     np.testing.assert_allclose(rstd.cpu().numpy(), 1.0 / np.sqrt(xs.var(axis=1) + 1e-5), rtol=2e-5)
-
-
-def test_fuzz_wide_backward_opt_in():
-    """round 4's four-wave backward (csrc/hstu_attn_bwd_wide.cuh; slower than the folded kernel, so opt-in) stays correct:
-    the head-dim-128 backward tests and a sweep slice in a child process with HSTU_BWD_WIDE=1 (the switch is read once per
-    process)."""
-    env = dict(os.environ, HSTU_BWD_WIDE="1")
-    code = ("import sys; sys.path.insert(0, 'tools'); import fuzz_attention as F\n"
-            "from generative_recommenders_amd.ops import _launch; import torch\n"
-            "assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 200).startswith('hstu_attn_bwd_wide_kernel')\n"
-            "f = 0\n"
-            "for n in (1, 33, 97, 160, 193, 200, 224):\n"
-            "    f += F.mha_sweep(2, seed=4600 + n, force_n=[n], exit_process=False, force_d=128)[0]\n"
-            "f += F.mha_sweep(2, seed=4700, big=True, force_n=[200, 185], exit_process=False, force_d=128)[0]\n"
-            "sys.exit(1 if f else 0)\n")
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_attention_gpu.py", "-q", "-m", "gpu", "-x", "-k",
-                        "batch_composition or strided_fused or (fold_backward_every_tile_count and 128 and dtype0)"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

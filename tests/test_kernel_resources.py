@@ -80,8 +80,6 @@ def test_no_kernel_spills_or_uses_scratch():
     # The fused LayerNorm + projection kernel's instantiation that also writes the normalised rows (backward's recompute): 8
     # registers of its extra addressing live in scratch across the row prologue; the forward's instantiation may not spill.
     bounded.update({"hstu_ln_linear_fwd_kernelIDF16bLb1E": 8, "hstu_ln_linear_fwd_kernelIDF16_Lb1E": 8})
-    # ... and its two-workgroups-per-CU arrangement (HSTU_LNL_SPLIT=1, an experiment: csrc/hstu_ln_linear2.cuh)
-    bounded.update({"hstu_ln_linear_fwd2_kernel": 40})
     bad = {k: v for k, v in ks.items() if (v["spill"] or v["scratch"]) and "hstu" in k and not any(a in k for a in accepted)
            and not any(b in k and v["spill"] <= n for b, n in bounded.items())}
     assert not bad, f"kernels with register spills / scratch: {bad}"
@@ -99,27 +97,3 @@ def test_hot_kernels_stay_under_their_occupancy_limits():
     assert fold64[0]["vgpr"] <= 256, fold64
     lnl = find("hstu_ln_linear_fwd_kernelIDF16bLb0E")                  # two waves per SIMD, the rows of x in 128 of the registers
     assert len(lnl) == 1 and lnl[0]["vgpr"] <= 256 and lnl[0]["spill"] == 0, lnl
-
-
-def test_wide_backward_owns_the_accumulator_file_and_passes_the_asm_lint():
-    """round 4's four-wave backward (opt-in: HSTU_BWD_WIDE=1) issues every MFMA through inline asm and owns all 256 AGPRs by
-    literal register names: one wave per SIMD (<= 512 registers), no spill, and the checks of tools/lint_asm_mfma.py on the
-    code hipcc emits (no compiler instruction in the accumulator file, none touching a chain's accumulators inside the chain,
-    two wait states in front of every MFMA)."""
-    ks = _kernels()
-    wide = [v for k, v in ks.items() if "hstu_attn_bwd_wide_kernel" in k]
-    assert len(wide) == 2, list(ks)                # bf16, f16
-    for v in wide:
-        assert v["vgpr"] <= 512 and v["spill"] == 0 and v["scratch"] == 0, v
-    import importlib.util
-
-    spec = importlib.util.spec_from_file_location("lint_asm_mfma", os.path.join(ROOT, "tools", "lint_asm_mfma.py"))
-    lint = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(lint)
-    csrc = os.path.join(ROOT, "generative_recommenders_amd", "csrc")
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "wide.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I.", "-I../../include",
-                        "--cuda-device-only", "-S", "attn_wide_bf16.hip", "-o", out], cwd=csrc, check=True, stderr=subprocess.DEVNULL)
-        findings, n = lint.lint(out, "hstu_attn_bwd_wide")
-    assert n > 200 and not findings, findings[:10]

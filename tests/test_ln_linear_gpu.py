@@ -158,34 +158,6 @@ def test_stu_layer_with_fused_ln_uvqk_matches_two_kernel_path(recompute, fuse_la
         assert rel < 3e-3, f"{n}: {rel:.3e}"
 
 
-def test_two_workgroups_per_cu_arrangement_matches():
-    """HSTU_LNL_SPLIT=1 (csrc/hstu_ln_linear2.cuh: two four-wave workgroups per CU, half-K ring tiles; measured slower, opt-in)
-    computes the same chains in the same order: bit-identical y.  Its own process: the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from test_ln_linear_gpu import _inputs, _fused\n"
-        "for rows, n in ((4099, 2048), (70000, 512), (257, 96)):\n"
-        "    x, lw, lb, w, b = _inputs(rows, n, torch.bfloat16, seed=rows)\n"
-        "    y = _fused(x, lw, lb, w, b, 1e-6, want_normed=False)[0]\n"
-        "    torch.save(y.cpu(), sys.argv[1] + f'.{rows}.pt')\n" % (root, os.path.join(root, "tests")))
-    import tempfile
-
-    with tempfile.TemporaryDirectory() as td:
-        outs = {}
-        for split in ("0", "1"):
-            env = dict(os.environ, HSTU_LNL_SPLIT=split)
-            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "y" + split)], env=env, capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs[split] = [torch.load(os.path.join(td, f"y{split}.{rows}.pt")) for rows in (4099, 70000, 257)]
-        for a, b in zip(outs["0"], outs["1"]):
-            assert torch.equal(a, b)
-
-
 def test_public_uvqk_op_runs_the_fused_kernel_forward_backward_and_row_results_do_not_depend_on_the_batch():
     """`hstu_compute_uqvk` (ops/hstu_compute.py:50-89) at embedding dim 512 with bf16 activations and fp32 master parameters:
     u, q, k, v and every gradient against fp64 autograd on the same bf16-representable inputs (relative Frobenius: q / k / v

@@ -74,11 +74,10 @@ def test_16bit_kernels_against_exact_and_rounded_reference(idx, dtype):
 
 
 def test_the_headline_backward_is_the_folded_kernel():
-    """what bench.py times: ask the library which backward it dispatches for the metric shape (HSTU_BWD_WIDE=1 opts into
-    round 4's four-wave experiment, which measured slower)"""
+    """what bench.py times: ask the library which backward it dispatches for the metric shape"""
     from generative_recommenders_amd.ops import _launch
 
-    want = "hstu_attn_bwd_wide_kernel" if os.environ.get("HSTU_BWD_WIDE", "0")[:1] == "1" else "hstu_attn_bwd_fold_kernel"
+    want = "hstu_attn_bwd_fold"
     assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 200).startswith(want)
     assert _launch.attn_bwd_kernel_name(torch.bfloat16, 64, 64, 200).startswith("hstu_attn_bwd_quad_kernel")
     assert _launch.attn_bwd_kernel_name(torch.float32, 128, 128, 200).startswith("hstu_attn_bwd_kernel")
