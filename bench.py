@@ -344,7 +344,7 @@ class Telemetry:
 
         try:
             out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20).stdout
-            card = next(iter(json.loads(out).values()))
+            card = next(iter(json.loads(out[out.index("{"):]).values()))
             return {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "power", "temperature"))}
         except Exception as e:
             return {"error": repr(e)[:200]}

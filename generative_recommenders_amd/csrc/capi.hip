@@ -104,6 +104,11 @@ int hstu_attn_bwd(const HstuAttnBwdParams* p, void* stream) {
     return set_error(HSTU_EINVAL, "hstu_attn_bwd: gradient base pointers must be 16-byte aligned");
   if (p->fwd.pos_w && (!p->dpos_w || (p->fwd.ts_w && !p->dts_w)))
     return set_error(HSTU_EINVAL, "hstu_attn_bwd: dpos_w / dts_w outputs are required with a relative bias");
+  // ahead of every dispatch decision (solo_bias, fold_bias and the general bias kernel all add their table gradients with
+  // float atomics into LDS histograms): refused rather than silently not honoured
+  if (p->fwd.pos_w && p->deterministic)
+    return set_error(HSTU_EUNSUPPORTED, "hstu_attn_bwd: deterministic = 1 is not available with the relative bias (the table gradients are "
+                                        "histograms of float atomics)");
   if (p->fwd.batch == 0 || p->total_rows == 0) return HSTU_OK;
   if (attn_bwd_workspace_bytes(*p) > 0 && !p->workspace)
     return set_error(HSTU_EINVAL, "hstu_attn_bwd: this shape needs %zu bytes of workspace", attn_bwd_workspace_bytes(*p));

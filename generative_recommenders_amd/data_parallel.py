@@ -26,6 +26,17 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not dist.is_initialized():
+        # Hosts whose driver only supports dmabuf IPC: without this RCCL's buffer exchange fails in hipIpcGetMemHandle.  The HSA
+        # runtime reads it when the process first touches the GPU -- so it only helps when nothing has touched it yet.
+        if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                import warnings
+
+                warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY is not set and the GPU runtime is already initialised: on dmabuf-only hosts "
+                              "RCCL will fail with 'hipIpcGetMemHandle: invalid argument'; export HSA_ENABLE_IPC_MODE_LEGACY=0 before "
+                              "the first torch.cuda call")
+            else:
+                os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:

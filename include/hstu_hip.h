@@ -124,8 +124,9 @@ typedef struct HstuAttnBwdParams {
   int deterministic;      /* ABI v8: != 0 -> every sum in a fixed order (hstu::hstu_mha_bwd's `deterministic`, flash_api.cpp:291;
                            * the CUDA reference serialises its dQ adds with a semaphore, flash_common.cpp:806-858).  One key block
                            * (the folded / 4-wave / one-wave kernels): always the case.  Several key blocks: each block's fp32 dq
-                           * partial goes to a slab of its own and the slabs are added in block order (workspace grows by the
-                           * number of key blocks: hstu_attn_bwd_workspace_bytes accounts for it).  With the research-path bias
+                           * partial goes to a slab of its own and the slabs are added in block order (workspace = number of key
+                           * blocks x total_rows x heads x dqk x 4 bytes, all of it zeroed and read back: at max_seq_len 8192 that
+                           * is dozens of slabs -- hstu_attn_bwd_workspace_bytes reports it, size the batch accordingly).  With the research-path bias
                            * (table gradients are histograms of float atomics) the call is refused: HSTU_EUNSUPPORTED. */
 } HstuAttnBwdParams;
 

@@ -1,0 +1,151 @@
+"""GPU tests of the ABI v10 glue around the projections: the multi-tensor parameter cast (bit-exact: it is a cast), the
+column sums behind the bias gradient (fp64 oracle, bit-identical run to run), the side-stream placement of those sums,
+and the rule that a call which tracks gradients never multiplies by a cached copy of a parameter."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_cast_params_is_the_torch_cast_bit_for_bit(dtype):
+    from generative_recommenders_amd.ops import _launch
+
+    g = torch.Generator().manual_seed(1)
+    shapes = [(512,), (512,), (512, 2048), (2048,), (4,), (4,), (1536, 512)]
+    params = [(torch.randn(*s, generator=g) * 3).to(DEV) for s in shapes]
+    outs = _launch.cast_params(params, dtype, transpose_index=2)
+    for i, (p, o) in enumerate(zip(params, outs)):
+        want = p.t().contiguous().to(dtype) if i == 2 else p.to(dtype)
+        assert o.shape == want.shape and o.dtype == dtype and o.is_contiguous()
+        assert o.data_ptr() % 16 == 0
+        assert torch.equal(o, want), i
+    # odd sizes, a non-square transposed item that is not a multiple of the 32 x 32 tile, one item only
+    odd = [torch.randn(37, 91, generator=g).to(DEV), torch.randn(5, generator=g).to(DEV), torch.randn(1, generator=g).to(DEV)]
+    o2 = _launch.cast_params(odd, dtype, transpose_index=0)
+    assert torch.equal(o2[0], odd[0].t().contiguous().to(dtype)) and torch.equal(o2[1], odd[1].to(dtype)) and torch.equal(o2[2], odd[2].to(dtype))
+    (o3,) = _launch.cast_params([odd[0]], dtype)
+    assert torch.equal(o3, odd[0].to(dtype))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 8), (7, 2048), (4099, 2048), (70001, 512), (300, 4096), (5, 40)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_column_sum_against_fp64_and_run_to_run(rows, cols, dtype):
+    from generative_recommenders_amd.ops import _launch
+
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(dtype).to(DEV)
+    got = _launch.column_sum(x)
+    again = _launch.column_sum(x)
+    assert got.dtype == torch.float32 and torch.equal(got, again)            # fixed summation order
+    want = x.double().sum(dim=0).cpu().numpy()
+    err = np.abs(got.double().cpu().numpy() - want)
+    # fp32 accumulation of `rows` 16-bit values: a few ulps of the running sum's magnitude
+    assert (err <= 2e-6 * (np.abs(x.double()).sum(dim=0).cpu().numpy() + 1e-30) + 1e-30).all(), err.max()
+    # a column slice of a wider buffer (the u / v / q / k quarters of d uvqk)
+    if cols >= 16:
+        wide = torch.randn(rows, cols + 24, generator=g).to(dtype).to(DEV)
+        sl = wide[:, 8 : 8 + cols]
+        assert _launch.column_sum_supported(sl)
+        assert torch.equal(_launch.column_sum(sl), _launch.column_sum(sl.contiguous()))
+
+
+def test_column_sum_argument_checks():
+    from generative_recommenders_amd import _lib as L
+    from generative_recommenders_amd.ops import _launch
+
+    assert not _launch.column_sum_supported(torch.zeros(4, 12, device=DEV, dtype=torch.bfloat16))     # 12 columns: not a multiple of 8
+    assert not _launch.column_sum_supported(torch.zeros(4, 16, device=DEV, dtype=torch.float32))
+    x = torch.zeros(4, 16, device=DEV, dtype=torch.bfloat16)
+    out = torch.empty(16, device=DEV, dtype=torch.float32)
+    rc = L.lib().hstu_column_sum(x.data_ptr(), 16, 4, 16, out.data_ptr(), None, 0, None)
+    assert rc == -1 and b"workspace" in L.lib().hstu_last_error()
+    rc = L.lib().hstu_column_sum(x.data_ptr(), 16, 0, 16, out.data_ptr(), None, 0, None)               # no rows: zeros
+    torch.cuda.synchronize()
+    assert rc == 0 and float(out.abs().sum()) == 0.0
+
+
+def _layer_and_input(dtype=torch.bfloat16, rows=777, seed=0):
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig
+
+    torch.manual_seed(seed)
+    layer = STULayer(STULayerConfig(embedding_dim=512, num_heads=4, hidden_dim=128, attention_dim=128, output_dropout_ratio=0.0,
+                                    use_group_norm=True)).to(DEV)
+    g = torch.Generator().manual_seed(seed + 1)
+    lengths = torch.tensor([200, 177, 200, 200], dtype=torch.int64)
+    off = torch.zeros(5, dtype=torch.int64)
+    off[1:] = torch.cumsum(lengths, 0)
+    x = torch.randn(int(off[-1]), 512, generator=g).to(dtype).to(DEV)
+    return layer, x, lengths.to(DEV), off.to(DEV)
+
+
+def _run(layer, x, lengths, off):
+    return layer(x=x, x_lengths=lengths, x_offsets=off, max_seq_len=200, num_targets=None)
+
+
+def test_training_calls_never_multiply_by_a_cached_parameter_copy():
+    """round-4 advisor finding: a copy cached per parameter VERSION misses writes through ``.data`` (its counter stays put).
+    A call that tracks gradients casts its parameters every time; the inference cache follows the version counter and has
+    an explicit invalidate hook for ``.data`` writers."""
+    from generative_recommenders_amd.ops import hstu_compute as HC
+
+    layer, x, lengths, off = _layer_and_input()
+    layer.train()
+    y0 = _run(layer, x, lengths, off).detach().clone()
+    v0 = layer._uvqk_weight._version
+    layer._uvqk_weight.data.mul_(1.5)                         # does not bump the version counter
+    layer._output_weight.data.mul_(0.5)
+    assert layer._uvqk_weight._version == v0
+    y1 = _run(layer, x, lengths, off).detach().clone()
+    assert not torch.equal(y0, y1), "training forward used a stale copy of a weight changed through .data"
+    # an optimizer step (version bump) is seen as well
+    opt = torch.optim.SGD(layer.parameters(), lr=0.5)
+    _run(layer, x, lengths, off).float().pow(2).mean().backward()
+    opt.step()
+    y2 = _run(layer, x, lengths, off).detach().clone()
+    assert not torch.equal(y1, y2)
+    # inference: cached per version -- bit-identical to a fresh cast, follows an in-place update, and the hook covers .data
+    layer.eval()
+    with torch.no_grad():
+        a = _run(layer, x, lengths, off).clone()
+        b = _run(layer, x, lengths, off).clone()
+        assert torch.equal(a, b) and len(HC._PARAM_CACHE) > 0
+        HC.invalidate_parameter_caches()
+        assert torch.equal(_run(layer, x, lengths, off), a)
+        layer._uvqk_weight.mul_(1.25)                           # in-place op on the parameter: version bump
+        c = _run(layer, x, lengths, off).clone()
+        assert not torch.equal(a, c)
+        layer._uvqk_weight.data.mul_(1.25)                      # through .data: invisible to the cache until invalidated
+        HC.invalidate_parameter_caches()
+        d = _run(layer, x, lengths, off).clone()
+        assert not torch.equal(c, d)
+
+
+def test_bias_gradient_on_the_side_stream_equals_the_in_stream_one():
+    """HSTU_DBETA_STREAM places hstu_column_sum on a side stream under the GEMMs that follow; the result and every other
+    gradient are the same tensors bit for bit"""
+    from generative_recommenders_amd.ops import hstu_compute as HC
+
+    layer, x, lengths, off = _layer_and_input(seed=3)
+    layer.train()
+    gy = torch.randn_like(x)
+    grads = {}
+    for mode in (True, False):
+        HC._DBETA_STREAM = mode
+        try:
+            for p in layer.parameters():
+                p.grad = None
+            xx = x.clone().requires_grad_()
+            _run(layer, xx, lengths, off).backward(gy)
+            torch.cuda.synchronize()
+            grads[mode] = [xx.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            HC._DBETA_STREAM = True
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)
+    # and against the torch reduction it replaces
+    beta = dict(layer.named_parameters())["_uvqk_beta"].grad
+    assert beta is not None and torch.isfinite(beta).all() and float(beta.abs().sum()) > 0
