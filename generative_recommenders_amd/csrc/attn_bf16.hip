@@ -9,7 +9,6 @@ int launch_attn_fwd_bf16(const HstuAttnParams& p, hipStream_t st) {
 int launch_attn_bwd_bf16(const HstuAttnBwdParams& p, hipStream_t st) {
   if (attn_solo_applicable(p.fwd, true)) return launch_attn_bwd_solo_bf16(p, st);
   if (attn_solo_bias_applicable(p.fwd, true)) return launch_attn_bwd_solo_bias_bf16(p, st);
-  if (attn_bwd_w16_applicable(p)) return launch_attn_bwd_w16_bf16(p, st);
   if (attn_bwd_fold_applicable(p)) return launch_attn_bwd_fold_bf16(p, st);
   return p.fwd.pos_w ? launch_attn_bwd_bias_bf16(p, st) : launch_bwd_dtype<bf16_t>(p, st);
 }

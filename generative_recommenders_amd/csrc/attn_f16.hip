@@ -9,7 +9,6 @@ int launch_attn_fwd_f16(const HstuAttnParams& p, hipStream_t st) {
 int launch_attn_bwd_f16(const HstuAttnBwdParams& p, hipStream_t st) {
   if (attn_solo_applicable(p.fwd, true)) return launch_attn_bwd_solo_f16(p, st);
   if (attn_solo_bias_applicable(p.fwd, true)) return launch_attn_bwd_solo_bias_f16(p, st);
-  if (attn_bwd_w16_applicable(p)) return launch_attn_bwd_w16_f16(p, st);
   if (attn_bwd_fold_applicable(p)) return launch_attn_bwd_fold_f16(p, st);
   return p.fwd.pos_w ? launch_attn_bwd_bias_f16(p, st) : launch_bwd_dtype<f16_t>(p, st);
 }

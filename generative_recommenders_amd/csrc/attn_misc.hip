@@ -33,15 +33,6 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 
-// head dim 128 of the folded shapes, no attention window: the sixteen-wave schedule (hstu_attn_bwd_w16.cuh).  Round 5's
-// structural experiment; HSTU_BWD_W16=1 selects it, =0 deselects it, unset: kW16Default.
-constexpr bool kW16Default = false;
-bool attn_bwd_w16_applicable(const HstuAttnBwdParams& bp) {
-  static const int mode = [] { const char* e = getenv("HSTU_BWD_W16"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
-  const bool enabled = mode < 0 ? kW16Default : mode == 1;
-  return enabled && attn_bwd_fold_applicable(bp) && bp.fwd.dqk == 128 && bp.fwd.dv == 128 && bp.fwd.max_attn_len == 0;
-}
-
 bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {
   static const bool enabled = [] { const char* e = getenv("HSTU_SOLO"); return !(e && e[0] == '0'); }();
   if (!enabled || p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.delta_q != 0) return false;
@@ -124,7 +115,6 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   if (p.pos_w && a != v) { buf[0] = 0; return set_error(HSTU_EUNSUPPORTED, "relative-bias attention is instantiated for dqk == dv"); }
   if (attn_solo_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_kernel<%s>", bwd ? "bwd" : "fwd", dt);
   else if (attn_solo_bias_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_bias_kernel<%s>", bwd ? "bwd" : "fwd", dt);
-  else if (bwd && attn_bwd_w16_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_w16_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
   else if (bwd && attn_bwd_fold_bias_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_bias_kernel<%s,64>", dt);

@@ -108,20 +108,35 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ x
   *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
 }
 
+// partial (groups, cols) -> out (cols): block = 64 columns x 4 group quarters, each thread adds its quarter's partials in group
+// order (four independent running sums), the four quarters are added in order through LDS: a fixed summation order
 __global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __restrict__ partial, int groups, int cols,
                                                                  float* __restrict__ out) {
-  // one wave per 16 columns x 4 group quarters would be faster; this is ~1 MB of fp32 at most: one thread per column
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int g = 0; g < groups; ++g) s += partial[(int64_t)g * cols + c];
-  out[c] = s;
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, qt = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (groups + 3) / 4;
+  const int g0 = qt * per, g1 = min(g0 + per, groups);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+      s0 += partial[(int64_t)g * cols + c];
+      s1 += partial[(int64_t)(g + 1) * cols + c];
+      s2 += partial[(int64_t)(g + 2) * cols + c];
+      s3 += partial[(int64_t)(g + 3) * cols + c];
+    }
+    for (; g < g1; ++g) s0 += partial[(int64_t)g * cols + c];
+  }
+  part[qt][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (qt == 0 && c < cols) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 static int column_sum_groups(int64_t rows, int cols) {
   static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int col_blocks = (cols / 8 + 255) / 256;
-  int64_t g = (int64_t)n_cu * 8 / col_blocks;       // 8 workgroups of 4 waves per CU
+  int64_t g = (int64_t)n_cu * 3 / col_blocks;       // 3 workgroups of 4 waves per CU, 8 rows of 16 bytes per lane in flight
   if (g > rows) g = rows;
   if (g > kColSumGroupsMax) g = kColSumGroupsMax;
   return g < 1 ? 1 : (int)g;
@@ -220,10 +235,10 @@ int hstu_column_sum(const void* x, int64_t ldx, int64_t rows, int32_t cols, floa
   const int groups = column_sum_groups(rows, cols);
   const dim3 grid(groups, (cols / 8 + 255) / 256);
   float* partial = (float*)workspace;
-  if (dtype == HSTU_DTYPE_BF16) hipLaunchKernelGGL((column_sum_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, cols, partial);
-  else hipLaunchKernelGGL((column_sum_kernel<f16_t, 4>), grid, dim3(256), 0, st, (const f16_t*)x, ldx, rows, cols, partial);
+  if (dtype == HSTU_DTYPE_BF16) hipLaunchKernelGGL((column_sum_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, cols, partial);
+  else hipLaunchKernelGGL((column_sum_kernel<f16_t, 8>), grid, dim3(256), 0, st, (const f16_t*)x, ldx, rows, cols, partial);
   if (int e = check_launch("hstu_column_sum")) return e;
-  hipLaunchKernelGGL(column_sum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partial, groups, cols, out);
+  hipLaunchKernelGGL(column_sum_finish_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, partial, groups, cols, out);
   return check_launch("hstu_column_sum(finish)");
 }
 

@@ -25,11 +25,6 @@ int launch_attn_bwd_bias_f32(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_bf16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_f16(const HstuAttnBwdParams& p, hipStream_t st);
 bool attn_bwd_fold_applicable(const HstuAttnBwdParams& p);
-// ... and, among those, head dim 128 without an attention window: sixteen waves per workgroup, 16-key ownership
-// (hstu_attn_bwd_w16.cuh; HSTU_BWD_W16=0 / 1 overrides the default)
-int launch_attn_bwd_w16_bf16(const HstuAttnBwdParams& p, hipStream_t st);
-int launch_attn_bwd_w16_f16(const HstuAttnBwdParams& p, hipStream_t st);
-bool attn_bwd_w16_applicable(const HstuAttnBwdParams& p);
 // short sequences (max_seq_len <= 64, head dims <= 32, 16-bit I/O): one wave per (user, head) (hstu_attn_solo.cuh; HSTU_SOLO=0 disables)
 int launch_attn_fwd_solo_bf16(const HstuAttnParams& p, hipStream_t st);
 int launch_attn_fwd_solo_f16(const HstuAttnParams& p, hipStream_t st);

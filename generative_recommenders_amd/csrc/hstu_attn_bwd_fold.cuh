@@ -66,6 +66,10 @@
 #ifndef FOLD_L2_TOUCH
 #define FOLD_L2_TOUCH 0    // (measured: no gain, profiles/r04_fold_dq32_l2touch.txt) 1: the NEXT step's Q / dO tiles are pulled into L2 while this step's pairs run; 2: and, in the last step, the
 #endif                     // next problem's first Q / dO tiles and its K / V tiles 0..3
+#ifndef FOLD_VMCNT_COUNTED
+#define FOLD_VMCNT_COUNTED 0   // (measured 1-2 % SLOWER, bit-identical: profiles/r05_fold_vmcnt_counted.txt) 1: the wait at the top of a step leaves the
+#endif                         // previous step's STORES in flight: vmcnt counts in issue order, and behind the stage requests a wave has only
+                               // its copy-out and dQ stores (head dim 128, 32x32x16 dQ chains)
 #ifndef FOLD_PERSIST
 #define FOLD_PERSIST 2     // 0: one workgroup per (user, head); 1: one workgroup per CU walks the problems; 2: and issues the
 #endif                     // next problem's K/V tiles of the slots its own tail does not use
@@ -794,10 +798,21 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
     }
   }
 
+  // stores this wave has DEFINITELY issued behind the stage requests of the previous step (a store whose lanes are all
+  // inactive may or may not count: leaving it out only makes the wait stricter)
+  int behind = 0;
+  constexpr bool kCounted = FOLD_VMCNT_COUNTED && !FOLD_ABLATE && !FOLD_L2_TOUCH && !FOLD_COPY_SPLIT && FOLD_DQ32 && DQK == 128 && DV == 128 && !BX::on;
   for (int k = 0; k < ns; ++k) {
     const int a = nt - 1 - k, bq = k;
     const bool b_on = bq < a;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kCounted && k > 0 && mc.win == 0) {
+      // the stage requests of step k were the first memory instructions behind barrier 1 of step k-1: only they have to land
+      if (behind >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (behind >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();   // Q/dO tiles of this step (and, first time, K/V) landed; dS' of the last step consumed
     HSTU_MARK(10);
     if constexpr (FOLD_L2_TOUCH && !BX::on && DQK == 128) {
@@ -851,6 +866,7 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
       fold_copy_out<T, DV, NTH>(smem + kt1 * C::PAIR + C::KT, dv_head + (int64_t)(32 * kt1) * dv_rs, dv_rs, len - 32 * kt1, t0);
     };
     if (k > 0 && !copy_split) copy_out_prev(std::integral_constant<int, kBwdThreads>{}, tid);
+    behind = (k > 0 && 4 * wave < len - 32 * (a + 1)) ? 2 : 0;      // (dk and dv: rows 4 wave .. 4 wave + 3 of the parked tile)
     HSTU_MARK(18);
     // ---- phase 2: dQ of the two query tiles, 16 feature columns per wave
     int lane2 = lane;
@@ -860,6 +876,7 @@ HSTU_DEV void fold_problem_x(const HstuAttnBwdParams& bp, int tmax, int uh, int 
       if constexpr (FOLD_DQ32 && DQK == 128 && DV == 128 && !BX::on) {
         if (mc.win == 0) {
           fold_dq_phase32<T, DQK>(bp, mc, smem, dsbuf, a, bq, b_on, wave, off0, hd, ds_scale, lane2 HSTU_TRACE_PASS);
+          behind += ((wave >> 2) == 0 || b_on) ? 2 : 0;               // (two 16-byte stores per lane, 32 query rows of an existing tile)
           done32 = true;
         }
       }

@@ -187,9 +187,10 @@ def _prepare_params(params, dtype, kmajor_index, tracked):
 
 
 # d uvqk_beta = the column sums of d uvqk (triton_addmm.py:309): one HBM-bound read of (rows, 2048) 16-bit values
-# (hstu_column_sum, fixed summation order).  HSTU_DBETA_STREAM=1 (default) launches it on a side stream so that it runs
-# UNDER the two MFMA-bound GEMMs that read d uvqk next instead of in front of them; 0 keeps it on the caller's stream.
-_DBETA_STREAM = os.environ.get("HSTU_DBETA_STREAM", "1") != "0"
+# (hstu_column_sum, fixed summation order: 156 us at 204,800 x 2048 = 5.1 TB/s).  HSTU_DBETA_STREAM=1 launches it on a side stream
+# so that it runs UNDER the two MFMA-bound GEMMs that read d uvqk next instead of in front of them: measured no gain (layer step
+# 13.86 vs 13.88 ms, gpurun r05_call3: the GEMMs' workgroups fill the CUs) -- off by default, same results either way.
+_DBETA_STREAM = os.environ.get("HSTU_DBETA_STREAM", "0") == "1"
 _SIDE_STREAMS: dict = {}
 
 

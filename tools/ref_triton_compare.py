@@ -6,6 +6,7 @@ buffer), forward and backward timed with CUDA events after the autotuner has set
 largest absolute difference between the two.  Never imported by the package, the tests or bench.py.
 
     python tools/ref_triton_compare.py [--users 8192] [--workloads M-full,M-jag] [--iters 20]
+    python tools/ref_triton_compare.py --workloads C2-len --max-seq-len 211 --head-dim 64      (BASELINE config 2: ML-20M ops-path shape)
 """
 import argparse
 import os
@@ -23,6 +24,8 @@ def make(workload, B, N, H, d, dev):
     g = torch.Generator(device=dev).manual_seed(1001)
     if workload == "M-full":
         lengths = torch.full((B,), N, dtype=torch.int64, device=dev)
+    elif workload == "C2-len":       # BASELINE config 2 (ML-20M): lengths uniform in [1, N] as bench.py's C2, on the ops path (no bias)
+        lengths = torch.randint(1, N + 1, (B,), generator=g, device=dev, dtype=torch.int64)
     else:
         lengths = torch.randint(int(0.9 * N), N, (B,), generator=g, device=dev, dtype=torch.int64)
     off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
@@ -50,9 +53,12 @@ def main():
     ap.add_argument("--users", type=int, default=8192)
     ap.add_argument("--workloads", default="M-full,M-jag")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--max-seq-len", type=int, default=200)
+    ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--head-dim", type=int, default=128)
     a = ap.parse_args()
     dev = "cuda"
-    N, H, d = 200, 4, 128
+    N, H, d = a.max_seq_len, a.heads, a.head_dim
     alpha = d ** -0.5
     print(f"torch {torch.__version__}, device {torch.cuda.get_device_name(0)}")
     from generative_recommenders_amd.ops.hstu_attention import hstu_mha
