@@ -65,6 +65,18 @@ __global__ __launch_bounds__(256) void cast_params_kernel(const CastItems it) {
   }
 }
 
+// the two 16-bit values of a dword as fp32
+template <typename T> struct Pair16;
+template <> struct Pair16<bf16_t> {
+  static HSTU_DEV float lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+  static HSTU_DEV float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+};
+template <> struct Pair16<f16_t> {
+  typedef f16_t v2 __attribute__((ext_vector_type(2)));
+  static HSTU_DEV float lo(uint32_t w) { return (float)__builtin_bit_cast(v2, w)[0]; }
+  static HSTU_DEV float hi(uint32_t w) { return (float)__builtin_bit_cast(v2, w)[1]; }
+};
+
 // ---- column sums: thread = 8 consecutive 16-bit columns (16 bytes), rows dealt round-robin to the row groups of the grid;
 // partial[group][cols] fp32, then a second kernel adds the groups in index order (deterministic)
 constexpr int kColSumGroupsMax = 1024;
@@ -82,25 +94,21 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ x
   for (; r + (UNROLL - 1) * G < rows; r += UNROLL * G) {
     u32x4 v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) v[u] = *(const u32x4*)(x + (r + u * G) * ldx + c0);
+    for (int u = 0; u < UNROLL; ++u) v[u] = gload16(x + (r + u * G) * ldx + c0);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        typedef T t2 __attribute__((ext_vector_type(2)));
-        const t2 p = __builtin_bit_cast(t2, v[u][e]);
-        acc[2 * e] += (float)p[0];
-        acc[2 * e + 1] += (float)p[1];
+        acc[2 * e] += Pair16<T>::lo(v[u][e]);
+        acc[2 * e + 1] += Pair16<T>::hi(v[u][e]);
       }
   }
   for (; r < rows; r += G) {
-    const u32x4 v = *(const u32x4*)(x + r * ldx + c0);
+    const u32x4 v = gload16(x + r * ldx + c0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      typedef T t2 __attribute__((ext_vector_type(2)));
-      const t2 p = __builtin_bit_cast(t2, v[e]);
-      acc[2 * e] += (float)p[0];
-      acc[2 * e + 1] += (float)p[1];
+      acc[2 * e] += Pair16<T>::lo(v[e]);
+      acc[2 * e + 1] += Pair16<T>::hi(v[e]);
     }
   }
   float* dst = partial + g * cols + c0;

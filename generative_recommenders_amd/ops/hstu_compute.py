@@ -40,7 +40,7 @@ def hstu_compute_uqvk(
         # the fused LayerNorm + projection kernel (one autograd node), as the STU layer's nodes use it: the K / V rows a delta
         # call appends to a cache are then bit-identical to the ones the prefill wrote (a row's result does not depend on its
         # neighbours in the batch)
-        uvqk = _LnUvqkFunction.apply(x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, norm_eps)
+        uvqk = _LnUvqkFunction.apply(x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, norm_eps, torch.is_grad_enabled())
     else:
         norm_weight, norm_bias, uvqk_weight, uvqk_bias = (t.to(x.dtype) for t in (norm_weight, norm_bias, uvqk_weight, uvqk_bias))
         normed_x = layer_norm(x, weight=norm_weight, bias=norm_bias, eps=norm_eps)
@@ -67,10 +67,11 @@ class _LnUvqkFunction(torch.autograd.Function):
     gradients (hipBLASLt) + the layer-norm backward kernel, normed_x recomputed by the row kernel (as the STU layer's nodes do)."""
 
     @staticmethod
-    def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, eps):
+    def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, eps, grad_on=True):
+        # (``grad_on``: the caller's grad mode -- inside forward it is always off, and needs_input_grad ignores it)
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
         (nw, nb, w, beta), kmajor = _prepare_params((norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2,
-                                                    any(ctx.needs_input_grad[1:5]))
+                                                    grad_on and any(ctx.needs_input_grad[1:5]))
         uvqk, _, mean, rstd = _ln_uvqk(x, nw, nb, eps, w, kmajor, beta, want_normed=False)
         ctx.save_for_backward(x, nw, nb, mean, rstd, w)
         ctx.kmajor, ctx.eps = kmajor, eps
@@ -86,7 +87,7 @@ class _LnUvqkFunction(torch.autograd.Function):
         d_normed = _uvqk_dgrad(duvqk, w, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
-        return dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), None
+        return dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), None, None
 
 
 class _SiluFunction(torch.autograd.Function):
@@ -303,13 +304,13 @@ class _ComputeOutputFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, attn, u, x, norm_weight, norm_bias, output_weight, eps, num_heads, linear_dim, concat_ux,
-                group_norm, recompute_y, dropout_ratio=0.0, seed=0):
+                group_norm, recompute_y, dropout_ratio=0.0, seed=0, grad_on=True):
         # dropout (training): inside the norm kernel, on all of [u, attn, u * Norm(attn)] as the reference's
         # _ln_mul_dropout_fwd does (triton_hstu_linear.py:101-120); the mask is never stored -- the backward kernel and the
         # recompute of y regenerate it from the seed
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, output_weight.dtype)
         (norm_weight, norm_bias, output_weight), _ = _prepare_params((norm_weight, norm_bias, output_weight), x.dtype, None,
-                                                                      any(ctx.needs_input_grad[3:6]))
+                                                                      grad_on and any(ctx.needs_input_grad[3:6]))
         y, mean, rstd = _launch.norm_mul_fwd(attn, u, norm_weight, norm_bias, eps, num_heads, linear_dim, group_norm,
                                              concat_ux, dropout_ratio, seed)
         out = torch.addmm(x, y, output_weight)
@@ -334,7 +335,7 @@ class _ComputeOutputFunction(torch.autograd.Function):
         dWo = weight_grad_mm(y, dout, out_dtype=wo_dtype)
         dattn, du, dnw, dnb = _launch.norm_mul_bwd(dy, attn, u, nw, nb, mean, rstd, H, Ld, gn, cat, p_drop, seed)
         return (dattn, du, dout, dnw.to(nw_dtype), dnb.to(nb_dtype), dWo, None, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 def hstu_compute_output(
@@ -359,7 +360,8 @@ def hstu_compute_output(
     torch._assert(0.0 <= p_drop < 1.0, "dropout_ratio must be in [0, 1)")
     seed = draw_dropout_seed() if p_drop > 0.0 else 0
     return _ComputeOutputFunction.apply(attn, u, x, norm_weight, norm_bias, output_weight, norm_eps, num_heads,
-                                        linear_dim, concat_ux, group_norm, recompute_y_in_backward, p_drop, seed)
+                                        linear_dim, concat_ux, group_norm, recompute_y_in_backward, p_drop, seed,
+                                        torch.is_grad_enabled())
 
 
 class _PreprocessAndAttentionFunction(torch.autograd.Function):
@@ -371,10 +373,10 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, norm_weight, norm_bias, uvqk_weight, uvqk_bias, seq_offsets, num_targets, norm_eps,
                 num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
-                recompute_uvqk, recompute_normed_x, user_order=None):
+                recompute_uvqk, recompute_normed_x, user_order=None, grad_on=True):
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
         (norm_weight, norm_bias, uvqk_weight, uvqk_bias), ctx.kmajor = _prepare_params(
-            (norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2, any(ctx.needs_input_grad[1:5]))
+            (norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2, grad_on and any(ctx.needs_input_grad[1:5]))
         uvqk, normed_x, mean, rstd = _ln_uvqk(x, norm_weight, norm_bias, norm_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
                                               want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
@@ -431,7 +433,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=w_dtype)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
         return (dx, dnw.to(nw_dtype), dnb.to(nb_dtype), dW, bias_grad.result().to(beta_dtype), None, None, None, None, None, None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 class _STULayerFunction(torch.autograd.Function):
@@ -452,10 +454,12 @@ class _STULayerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight, seq_offsets, num_targets,
                 in_eps, out_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
-                recompute_uvqk, recompute_normed_x, recompute_y, concat_ux, group_norm, dropout_ratio, seed, user_order):
+                recompute_uvqk, recompute_normed_x, recompute_y, concat_ux, group_norm, dropout_ratio, seed, user_order,
+                grad_on=True):
         ctx.param_dtypes = tuple(t.dtype for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
         (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight), ctx.kmajor = _prepare_params(
-            (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight), x.dtype, 2, any(ctx.needs_input_grad[1:8]))
+            (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight), x.dtype, 2,
+            grad_on and any(ctx.needs_input_grad[1:8]))
         uvqk, normed_x, mean, rstd = _ln_uvqk(x, in_nw, in_nb, in_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
                                               want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
@@ -525,7 +529,7 @@ class _STULayerFunction(torch.autograd.Function):
         d_normed = _uvqk_dgrad(duvqk, W, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd, dresidual=dout)
-        return (dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), donw.to(dt[4]), donb.to(dt[5]), dWo) + (None,) * 19
+        return (dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), donw.to(dt[4]), donb.to(dt[5]), dWo) + (None,) * 20
 
 
 def hstu_fused_layer_applicable(x: torch.Tensor, attn_dim: int, hidden_dim: int) -> bool:
@@ -582,7 +586,7 @@ def hstu_fused_layer(
         x, input_norm_weight, input_norm_bias, uvqk_weight, uvqk_bias, output_norm_weight, output_norm_bias, output_weight,
         seq_offsets, num_targets, input_norm_eps, output_norm_eps, num_heads, attn_dim, hidden_dim, max_seq_len, attn_alpha,
         max_attn_len, contextual_seq_len, recompute_uvqk_in_backward, recompute_normed_x_in_backward,
-        recompute_y_in_backward, concat_ux, group_norm, p_drop, seed, order)
+        recompute_y_in_backward, concat_ux, group_norm, p_drop, seed, order, torch.is_grad_enabled())
 
 
 def hstu_preprocess_and_attention(
@@ -624,6 +628,7 @@ def hstu_preprocess_and_attention(
             attn_dim, hidden_dim, max_seq_len, attn_alpha, max_attn_len, contextual_seq_len,
             recompute_uvqk_in_backward, recompute_normed_x_in_backward,
             _launch.length_order(_launch._idx(seq_offsets)) if sort_by_length and seq_offsets.numel() > 2 else None,
+            torch.is_grad_enabled(),
         )
         return u, attn_output, None, None
     # prefill (k, v are returned for the KV cache) or head dims that need padding
