@@ -710,7 +710,7 @@ def cpu_baseline_layer(args, cores):
                        f"({med * 1e3:.0f} ms each); oracle/dense_torch.py::dense_stu_stack = reference modules/stu.py PyTorch path")
 
 
-TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def traffic_entry(workload, users, head_dim, heads):
