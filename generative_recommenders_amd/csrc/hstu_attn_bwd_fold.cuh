@@ -70,6 +70,12 @@
 #define FOLD_VMCNT_COUNTED 0   // (measured 1-2 % SLOWER, bit-identical: profiles/r05_fold_vmcnt_counted.txt) 1: the wait at the top of a step leaves the
 #endif                         // previous step's STORES in flight: vmcnt counts in issue order, and behind the stage requests a wave has only
                                // its copy-out and dQ stores (head dim 128, 32x32x16 dQ chains)
+#ifndef FOLD_ZERO_INIT
+#define FOLD_ZERO_INIT 1       // pairs that need no mask (strictly below the diagonal, all rows real: 21 of a 7-tile problem's 28) start their
+#endif                         // S chain from the MFMA's literal-zero C operand instead of running the 3-instructions-per-element mask set-up
+#ifndef FOLD_DS_FMA
+#define FOLD_DS_FMA 1          // dS' = dP (sg + P' (1 - sg)) instead of dP sg (1 + x (1 - sg)): one packed instruction per element pair less
+#endif
 #ifndef FOLD_PERSIST
 #define FOLD_PERSIST 2     // 0: one workgroup per (user, head); 1: one workgroup per CU walks the problems; 2: and issues the
 #endif                     // next problem's K/V tiles of the slots its own tail does not use
@@ -195,7 +201,7 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
   // (keep key <= query) and is it the sequence's last, partial query tile (keep query < len; every key of an earlier
   // tile is then < len too) -- both patterns live in one lane-constant register of the kernel (dmvm).  Any other
   // mask: the bits are collected from the general predicate.
-  {
+  auto mask_init = [&]() {
     int km = -1;
     if (mode == 1) km = ((k0 == i0) ? dmvm : -1) & ((i0 + 32 > len) ? (dmvm >> 16) : -1);
     if (mode == 2) {
@@ -212,9 +218,12 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
     for (int r = 0; r < 16; ++r) {
       const int m = ((int)(nk << (31 - r))) >> 31;        // all ones iff masked
       s[r] = __builtin_bit_cast(float, (unsigned)m & neg);
-      dp[r] = 0.f;
     }
-  }
+  };
+  constexpr bool kZeroInit = FOLD_ZERO_INIT && !BX::on;
+  if (!kZeroInit) mask_init();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dp[r] = 0.f;
   // S and dP as ONE stream of 16 MFMAs alternating between the two accumulators (no back-to-back dependency), with
   // the LDS reads of item m + AHEAD issued before the MFMA of item m.  The order is pinned with scheduling
   // barriers: left alone, hipcc emits read, read, wait, MFMA per item into the same registers, i.e. one full LDS
@@ -235,7 +244,18 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
     for (int m = 0; m < NM; ++m) {
       if (m + AHEAD < NM) load_item(m + AHEAD, fa[(m + AHEAD) % (AHEAD + 1)], fb[(m + AHEAD) % (AHEAD + 1)]);
       if (m & 1) dp = E::mma(fa[m % (AHEAD + 1)], fb[m % (AHEAD + 1)], dp);
-      else s = E::mma(fa[m % (AHEAD + 1)], fb[m % (AHEAD + 1)], s);
+      else if (kZeroInit && m == 0) {
+        // (wave-uniform) no mask: the chain starts from the MFMA's literal-zero C operand; otherwise from the mask pattern
+        if (mode == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          s = E::mma(fa[0], fb[0], z);
+        } else {
+          mask_init();
+          s = E::mma(fa[0], fb[0], s);
+        }
+      } else s = E::mma(fa[m % (AHEAD + 1)], fb[m % (AHEAD + 1)], s);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -308,8 +328,12 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
         const f32x2 dn = e + one2;
         const f32x2 sg = {__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])};
         const f32x2 pr = x * sg;
+#if FOLD_DS_FMA
+        const f32x2 dsr = dpv * (pr * (one2 - sg) + sg);     // sg (1 + x (1 - sg)) = sg + P' (1 - sg)
+#else
         const f32x2 w = x * (one2 - sg) + one2;     // 1 + x (1 - sg)
         const f32x2 dsr = dpv * sg * w;
+#endif
         pv[j] = pr[0]; pv[j + 1] = pr[1];
         dsv[j] = dsr[0]; dsv[j + 1] = dsr[1];
       }
