@@ -220,7 +220,7 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
       s[r] = __builtin_bit_cast(float, (unsigned)m & neg);
     }
   };
-  constexpr bool kZeroInit = FOLD_ZERO_INIT && !BX::on;
+  constexpr bool kZeroInit = FOLD_ZERO_INIT;     // (with the bias too: x = alpha S + b of an unmasked element needs no start value)
   if (!kZeroInit) mask_init();
 #pragma unroll
   for (int r = 0; r < 16; ++r) dp[r] = 0.f;

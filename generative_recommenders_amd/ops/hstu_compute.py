@@ -83,11 +83,11 @@ class _LnUvqkFunction(torch.autograd.Function):
         duvqk = duvqk.contiguous()
         normed_x, _, _ = _launch.layer_norm_fwd(x, nw, nb, ctx.eps)
         dt = ctx.param_dtypes
-        bias_grad = _BiasGrad(duvqk, dt[3])
+        dbeta = _bias_grad(duvqk, dt[3])
         d_normed = _uvqk_dgrad(duvqk, w, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
-        return dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), None, None
+        return dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, dbeta.to(dt[3]), None, None
 
 
 class _SiluFunction(torch.autograd.Function):
@@ -188,42 +188,14 @@ def _prepare_params(params, dtype, kmajor_index, tracked):
 
 
 # d uvqk_beta = the column sums of d uvqk (triton_addmm.py:309): one HBM-bound read of (rows, 2048) 16-bit values
-# (hstu_column_sum, fixed summation order: 156 us at 204,800 x 2048 = 5.1 TB/s).  HSTU_DBETA_STREAM=1 launches it on a side stream
-# so that it runs UNDER the two MFMA-bound GEMMs that read d uvqk next instead of in front of them: measured no gain (layer step
-# 13.86 vs 13.88 ms, gpurun r05_call3: the GEMMs' workgroups fill the CUs) -- off by default, same results either way.
-_DBETA_STREAM = os.environ.get("HSTU_DBETA_STREAM", "0") == "1"
-_SIDE_STREAMS: dict = {}
-
-
-class _BiasGrad:
-    """starts the column sums of ``duvqk`` (fp32); ``result()`` joins them into the caller's stream"""
-
-    def __init__(self, duvqk: torch.Tensor, out_dtype: torch.dtype):
-        self.side = None
-        if not _launch.column_sum_supported(duvqk):
-            self.out = duvqk.sum(dim=0, dtype=torch.float32 if out_dtype == torch.float32 else None)
-            return
-        if not _DBETA_STREAM:
-            self.out = _launch.column_sum(duvqk)
-            return
-        dev = duvqk.device
-        rows, cols = duvqk.shape
-        # allocated on the caller's stream (so that the caching allocator hands them back to it), written on the side stream
-        self.out = torch.empty(cols, dtype=torch.float32, device=dev)
-        ws = torch.empty(max(16, _launch.L.lib().hstu_column_sum_workspace_bytes(rows, cols)), dtype=torch.uint8, device=dev)
-        side = _SIDE_STREAMS.get(dev)
-        if side is None:
-            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            _launch.column_sum(duvqk, out=self.out, workspace=ws)
-        self.side, self._ws = side, ws
-
-    def result(self) -> torch.Tensor:
-        if self.side is not None:
-            torch.cuda.current_stream(self.out.device).wait_stream(self.side)   # (duvqk and the workspace outlive this point)
-            self.side = None
-        return self.out
+# (hstu_column_sum, fixed summation order: 152-157 us at 204,800 x 2048 = 5.1-5.2 TB/s).  (Launched on a side stream under the two
+# MFMA-bound GEMMs that read d uvqk next it measured no gain -- layer step 13.86 vs 13.88 ms, docs/EXPERIMENTS.md R5.4 -- so it
+# runs in stream order and the side-stream variant is gone.)
+def _bias_grad(duvqk: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """fp32 column sums of d uvqk (torch's reduction for layouts / dtypes the kernel does not take)"""
+    if _launch.column_sum_supported(duvqk):
+        return _launch.column_sum(duvqk)
+    return duvqk.sum(dim=0, dtype=torch.float32 if out_dtype == torch.float32 else None)
 
 
 def _uvqk_prepare(weight: torch.Tensor, dtype: torch.dtype):
@@ -428,11 +400,11 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                          dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         _launch.silu_bwd(du, uvqk[:, :hv], din=duvqk[:, :hv])
         nw_dtype, nb_dtype, w_dtype, beta_dtype = ctx.param_dtypes
-        bias_grad = _BiasGrad(duvqk, beta_dtype)
+        dbeta = _bias_grad(duvqk, beta_dtype)
         d_normed = _uvqk_dgrad(duvqk, W, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=w_dtype)
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd)
-        return (dx, dnw.to(nw_dtype), dnb.to(nb_dtype), dW, bias_grad.result().to(beta_dtype), None, None, None, None, None, None,
+        return (dx, dnw.to(nw_dtype), dnb.to(nb_dtype), dW, dbeta.to(beta_dtype), None, None, None, None, None, None,
                 None, None, None, None, None, None, None, None)
 
 
@@ -525,11 +497,11 @@ class _STULayerFunction(torch.autograd.Function):
         _launch.attn_bwd(dattn.view(-1, H, Hd), q, k, v, seq_offsets, num_targets, N, alpha, 1.0 / N, w, c, 0,
                          dq=dq, dk=dk, dv=dv, user_order=ctx.user_order)
         # ---- projections and the input norm (+ the residual's gradient, inside the kernel)
-        bias_grad = _BiasGrad(duvqk, dt[3])
+        dbeta = _bias_grad(duvqk, dt[3])
         d_normed = _uvqk_dgrad(duvqk, W, ctx.kmajor)
         dW = weight_grad_mm(normed_x, duvqk, out_dtype=dt[2])
         dx, dnw, dnb = _launch.layer_norm_bwd(d_normed, x, nw, mean, rstd, dresidual=dout)
-        return (dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, bias_grad.result().to(dt[3]), donw.to(dt[4]), donb.to(dt[5]), dWo) + (None,) * 20
+        return (dx, dnw.to(dt[0]), dnb.to(dt[1]), dW, dbeta.to(dt[3]), donw.to(dt[4]), donb.to(dt[5]), dWo) + (None,) * 20
 
 
 def hstu_fused_layer_applicable(x: torch.Tensor, attn_dim: int, hidden_dim: int) -> bool:
