@@ -116,15 +116,15 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ x
   *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
 }
 
-// partial (groups, cols) -> out (cols): block = 64 columns x 4 group quarters, each thread adds its quarter's partials in group
-// order (four independent running sums), the four quarters are added in order through LDS: a fixed summation order
+// partial (groups, cols) -> out (cols): block = 16 columns x 16 group sixteenths, each thread adds its share of the partials in group
+// order (four independent running sums), the sixteen shares are added in index order through LDS: a fixed summation order
 __global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __restrict__ partial, int groups, int cols,
                                                                  float* __restrict__ out) {
-  __shared__ float part[4][64];
-  const int cl = threadIdx.x & 63, qt = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int per = (groups + 3) / 4;
-  const int g0 = qt * per, g1 = min(g0 + per, groups);
+  __shared__ float part[16][17];
+  const int cl = threadIdx.x & 15, sh = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int per = (groups + 15) / 16;
+  const int g0 = sh * per, g1 = min(g0 + per, groups);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < cols) {
     int g = g0;
@@ -136,9 +136,14 @@ __global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __r
     }
     for (; g < g1; ++g) s0 += partial[(int64_t)g * cols + c];
   }
-  part[qt][cl] = (s0 + s1) + (s2 + s3);
+  part[sh][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (qt == 0 && c < cols) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+  if (sh == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][cl];
+    out[c] = t;
+  }
 }
 
 static int column_sum_groups(int64_t rows, int cols) {
@@ -246,7 +251,7 @@ int hstu_column_sum(const void* x, int64_t ldx, int64_t rows, int32_t cols, floa
   if (dtype == HSTU_DTYPE_BF16) hipLaunchKernelGGL((column_sum_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, cols, partial);
   else hipLaunchKernelGGL((column_sum_kernel<f16_t, 8>), grid, dim3(256), 0, st, (const f16_t*)x, ldx, rows, cols, partial);
   if (int e = check_launch("hstu_column_sum")) return e;
-  hipLaunchKernelGGL(column_sum_finish_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, partial, groups, cols, out);
+  hipLaunchKernelGGL(column_sum_finish_kernel, dim3((cols + 15) / 16), dim3(256), 0, st, partial, groups, cols, out);
   return check_launch("hstu_column_sum(finish)");
 }
 

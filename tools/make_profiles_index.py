@@ -19,7 +19,10 @@ def describe(path):
     try:
         if path.endswith(".json"):
             txt = open(path).read().strip()
-            d = json.loads(txt.splitlines()[-1]) if txt else {}
+            try:
+                d = json.loads(txt) if txt else {}
+            except ValueError:
+                d = json.loads(txt.splitlines()[-1])
             if isinstance(d, dict):
                 if "metric" in d and "value" in d:
                     r = d.get("roofline", {}) or {}
