@@ -77,7 +77,7 @@ def _event_ms(pairs):
     return statistics.mean(a.elapsed_time(b) for a, b in pairs)
 
 
-def attention_section(args, rank, world, device):
+def attention_section(args, rank, world, device, telem=None):
     """the timed region of the headline number: K steps of attention fwd (+ bwd), bracketed by barrier + synchronize"""
     from generative_recommenders_amd import data_parallel as dp
     from generative_recommenders_amd.ops import _launch
@@ -169,10 +169,15 @@ def attention_section(args, rank, world, device):
         kernels["bwd"] = _launch.attn_bwd_kernel_name(dtype, d, d, N, heads=H, alpha=alpha, **tg)
         finite = lambda o: bool(torch.isfinite(o.float()).all() and torch.isfinite(dfused.float()).all())
 
+    if telem is not None:
+        telem.start()
     for _ in range(args.warmup):
         fwd()
         if bwd is not None:
             bwd()
+    if telem is not None:
+        torch.cuda.synchronize()
+        telem.stop()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
@@ -201,6 +206,14 @@ def attention_section(args, rank, world, device):
     if bwd is not None:
         step_spread["bwd_ms"] = spread([e[1].elapsed_time(e[2]) for e in ev])
     assert finite(out), "non-finite values in the benchmark outputs"
+    if telem is not None:      # untimed replay of the same steps under the sampler (see Telemetry)
+        telem.start()
+        for _ in range(min(args.steps, 25)):
+            fwd()
+            if bwd is not None:
+                bwd()
+        torch.cuda.synchronize()
+        telem.stop()
     parity = None
     if getattr(args, "parity_users", 0) and wl in ("M-full", "M-jag", "M-targets", "C4") and rank == 0:
         try:
@@ -297,9 +310,13 @@ def copy_bandwidth(device):
 
 
 class Telemetry:
-    """Clocks / power / temperature of this rank's GPU sampled by a background thread while a section runs, so that a slow
-    box is visible in the bench line itself.  Source: the amdgpu sysfs nodes (hwmon freq1 = sclk, freq2 = mclk, power1,
-    temp1..3; no subprocess, ~50 us per sample); when they are not readable, one ``rocm-smi`` call before and after."""
+    """Clocks / power / temperature of this rank's GPU sampled by a background thread, so that a slow box is visible in the
+    bench line itself.  Source: the amdgpu sysfs nodes (hwmon freq1 = sclk, freq2 = mclk, power1, temp1..3; no subprocess);
+    when they are not readable, one ``rocm-smi`` call before and after.  The sampler NEVER runs inside a timed region: it
+    runs during the warm-up steps in front of it and during an untimed replay of the same steps behind it (the same kernels,
+    the same load).  Sampling inside the timed loop was the first version: one run of three then showed a single forward
+    step of 42 ms among fifty of 1.3 (gpurun r05b: the hwmon reads go through the SMU) -- 17 % of the headline from one
+    hiccup."""
 
     def __init__(self, device, period=0.02):
         import glob
@@ -359,22 +376,32 @@ class Telemetry:
                 pass
         return row
 
-    def __enter__(self):
+    def start(self):
+        """sample until stop(); may be called several times (the samples accumulate)"""
         import threading
 
-        if self.nodes:
+        if self.nodes and self._thread is None:
+            self._stop.clear()
+
             def loop():
                 while not self._stop.is_set():
                     self.samples.append(self._read())
                     self._stop.wait(self.period)
             self._thread = threading.Thread(target=loop, daemon=True)
             self._thread.start()
-        return self
 
-    def __exit__(self, *exc):
+    def stop(self):
         if self._thread is not None:
             self._stop.set()
             self._thread.join()
+            self._thread = None
+
+    def __enter__(self):
+        self.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
         return False
 
     def summary(self):
@@ -482,7 +509,7 @@ def rccl_section(world, device, nbytes=22 << 20):
                 busbw_GBps=2.0 * (world - 1) / world * nbytes / dt / 1e9)
 
 
-def layer_section(args, rank, world, device):
+def layer_section(args, rank, world, device, telem=None):
     """3 x STULayer (D=512, H=4, dqk=dv=128, group norm, target-aware) fwd+bwd + gradient
     all-reduce, bf16 activations (DLRM-v3 HSTU config, dlrm_v3/configs.py:30-41)."""
     from generative_recommenders_amd import data_parallel as dp
@@ -499,7 +526,7 @@ def layer_section(args, rank, world, device):
     gy = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen)
     nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
 
-    def timed(recompute, dropout, fuse=True):
+    def timed(recompute, dropout, fuse=True, telem=None):
         """recompute=True: the reference's STULayerConfig defaults (normed x, uvqk and y recomputed in the backward --
         a memory saving sized for 80 GB parts); False: everything kept (3 layers x 1024 users: 2.4 GB of 288).
         dropout: output_dropout_ratio of the layers (DLRM-v3 trains with hstu_linear_dropout_rate = 0.1,
@@ -522,8 +549,13 @@ def layer_section(args, rank, world, device):
             y.backward(gy)
             reducer.reduce()
 
+        if telem is not None:
+            telem.start()
         for _ in range(3):
             step()
+        if telem is not None:
+            torch.cuda.synchronize()
+            telem.stop()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -533,7 +565,14 @@ def layer_section(args, rank, world, device):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        return dp.max_over_ranks(time.perf_counter() - t0, device), stack
+        elapsed = dp.max_over_ranks(time.perf_counter() - t0, device)
+        if telem is not None:      # untimed replay under the sampler (see Telemetry)
+            telem.start()
+            for _ in range(min(args.layer_steps, 5)):
+                step()
+            torch.cuda.synchronize()
+            telem.stop()
+        return elapsed, stack
 
     p_drop = args.layer_dropout
     if getattr(args, "layer_tunableop", False):
@@ -545,7 +584,7 @@ def layer_section(args, rank, world, device):
     elapsed_keep, _ = timed(False, p_drop)
     elapsed_nodrop, _ = timed(True, 0.0)
     elapsed_two, _ = timed(True, p_drop, fuse=False)
-    elapsed, stack = timed(True, p_drop)
+    elapsed, stack = timed(True, p_drop, telem=telem)
     nparams = sum(p.numel() for p in stack.parameters())
     gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
     return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,
@@ -825,11 +864,7 @@ def run(args):
     _lib.lib()
 
     telem = Telemetry(device) if rank == 0 else None
-    if telem is not None:
-        with telem:
-            att = attention_section(args, rank, world, device)
-    else:
-        att = attention_section(args, rank, world, device)
+    att = attention_section(args, rank, world, device, telem)
     value = world * att["users"] * args.steps / att["elapsed"]
     N, H, d = args.max_seq_len, args.heads, args.head_dim
     what = "fwd" if att["fwd_only"] else "fwd+bwd"
@@ -859,7 +894,8 @@ def run(args):
         "(tests/test_attention_gpu.py); the reference-minted vectors at this head shape are "
         "tests/golden/metric_shapes.npz (N = 200, 4 x 128)")
     if telem is not None:
-        res["telemetry"] = {"headline": telem.summary()}
+        res["telemetry"] = {"headline": telem.summary(),
+                            "when": "sampled during the warm-up steps in front of each timed loop and an untimed replay of the same steps behind it, never inside a timed region"}
     attach_traffic(res, args, att)
     if args.workload == "M-full" and not args.no_extra:
         res["extra_workloads"] = extra_workloads(args, rank, world, device)
@@ -882,12 +918,9 @@ def run(args):
     if not args.no_layer:
         try:
             telem_l = Telemetry(device) if rank == 0 else None
+            res["layer"] = layer_section(args, rank, world, device, telem_l)
             if telem_l is not None:
-                with telem_l:
-                    res["layer"] = layer_section(args, rank, world, device)
                 res.setdefault("telemetry", {})["layer"] = telem_l.summary()
-            else:
-                res["layer"] = layer_section(args, rank, world, device)
             fused = res["layer"].get("projections", {}).get("uvqk_fwd_fused")
             if rank == 0 and fused and isinstance(res.get("calibration"), dict) and "mfma_stream_tflops" in res["calibration"]:
                 res["calibration"]["uvqk_fwd_fused_over_mfma_stream"] = round(fused["tflops"] / res["calibration"]["mfma_stream_tflops"], 3)
