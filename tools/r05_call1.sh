@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of the round's first GPU call; the sixteen-wave kernel it exercises has since left the library: docs/experiments/r05_*, HSTU_BWD_W16 is a no-op now)
 # Round-5 first GPU call: (1) the new glue ops + the layer tests, (2) the sixteen-wave backward against the tests of the folded
 # one, (3) A/B timing fold vs w16 on the metric shape (+ ablations), (4) the default bench line with the new sections.
 OUT=gpurun_out/r05_call1

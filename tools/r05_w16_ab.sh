@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record; needs the experiment's library builds -- see docs/EXPERIMENTS.md R5.1 for how they were made from commit 17e3774)
 # A/B of the sixteen-wave backward against the folded one on the metric shape (+ its ablation builds), correctness first
 OUT=gpurun_out/r05_w16_ab
 mkdir -p $OUT
