@@ -262,10 +262,8 @@ class GradientAllReducer:
             if world > 1 and self._sync and self.check_every > 0 and self._calls % self.check_every == 0:
                 ref = self.buckets[0][0]
                 nb = len(self.buckets)
-                state = torch.zeros(2 * nb, dtype=torch.int32, device=ref.device)
-                for bi in range(nb):
-                    state[bi] = 1 if bi in late else 0
-                    state[nb + bi] = 1 - int(state[bi])
+                bits = [1 if bi in late else 0 for bi in range(nb)]
+                state = torch.tensor(bits + [1 - b for b in bits], dtype=torch.int32, device=ref.device)
                 dist.all_reduce(state, op=dist.ReduceOp.MAX)
                 # a bucket late on some ranks and not on others shows up as 1 in BOTH halves -- on every rank
                 if bool((state[:nb] + state[nb:] > 1).any()):
