@@ -545,7 +545,7 @@ def layer_section(args, rank, world, device, telem=None):
     gy = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen)
     nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
 
-    def timed(recompute, dropout, fuse=True, telem=None):
+    def timed(recompute, dropout, fuse=True, telem=None, replay=0):
         """recompute=True: the reference's STULayerConfig defaults (normed x, uvqk and y recomputed in the backward --
         a memory saving sized for 80 GB parts); False: everything kept (3 layers x 1024 users: 2.4 GB of 288).
         dropout: output_dropout_ratio of the layers (DLRM-v3 trains with hstu_linear_dropout_rate = 0.1,
@@ -590,12 +590,14 @@ def layer_section(args, rank, world, device, telem=None):
         if world > 1:
             dist.barrier()
         elapsed = dp.max_over_ranks(time.perf_counter() - t0, device)
-        if telem is not None:      # untimed replay under the sampler (see Telemetry)
-            telem.start()
-            for _ in range(min(args.layer_steps, 5)):
+        if replay:      # untimed replay under rank 0's sampler (see Telemetry).  EVERY rank runs it: the steps contain collectives
+            if telem is not None:
+                telem.start()
+            for _ in range(replay):
                 step()
             torch.cuda.synchronize()
-            telem.stop()
+            if telem is not None:
+                telem.stop()
         return elapsed, stack
 
     p_drop = args.layer_dropout
@@ -608,7 +610,7 @@ def layer_section(args, rank, world, device, telem=None):
     elapsed_keep, _ = timed(False, p_drop)
     elapsed_nodrop, _ = timed(True, 0.0)
     elapsed_two, _ = timed(True, p_drop, fuse=False)
-    elapsed, stack = timed(True, p_drop, telem=telem)
+    elapsed, stack = timed(True, p_drop, telem=telem, replay=min(args.layer_steps, 5))
     nparams = sum(p.numel() for p in stack.parameters())
     gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
     return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,

@@ -18,6 +18,8 @@ for k,v in d['extra_workloads'].items(): print(' ', k, {x: v.get(x) for x in ('f
 L=d.get('layer'); print('layer', {k: L.get(k) for k in ('ms_per_step','error')} , {k: L[k]['ms_per_step'] for k in ('two_node_layers','dropout_off','no_recompute') if k in L}, L.get('projections'))
 print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
 PY
+echo "== two-rank rehearsal of the whole bench flow (gloo, both ranks on this GPU; a stall dumps the stacks)"
+WATCHDOG=150 LIMIT=400 bash tools/rehearse_two_ranks.sh 2>&1 | tail -3 | cut -c1-300
 echo "== rocprofv3: attention bench"
 bash tools/prof_pmc.sh ${TAG} > /dev/null 2>&1; head -24 gpurun_out/prof_${TAG}/summary.md
 echo "== rocprofv3: layer section"
