@@ -27,6 +27,7 @@ from oracle import hstu_oracle as O  # noqa: E402
 # relative Frobenius gates.  The test suite's (1.5 x the error measured on large tensors) are averages: a user of ONE row is a
 # handful of roundings and may sit at the format's worst case, half an ulp = 2^-8 (bf16) / 2^-11 (fp16) relative per element
 # -- so the sweep, which draws such users on purpose, gates at 1.5 x that worst case; fp32 as the suite.
+FP16_QUANTUM = 2.0 ** -24
 GATE = {torch.float32: 1.5e-6, torch.bfloat16: 1.5 * 2.0 ** -8, torch.float16: 1.5 * 2.0 ** -11}
 
 
@@ -205,11 +206,18 @@ def mha_sweep(cases, seed, big=False, force_n=None, exit_process=True, force_d=N
         for name, got, want in (("out", out, ref), ("dq", qd.grad, rq), ("dk", kd.grad, rk), ("dv", vd.grad, rv)):
             gnp = got.detach().double().cpu().numpy()
             den = np.linalg.norm(want)
-            rel = np.linalg.norm(gnp - want) / den if den > 0 else float(np.abs(gnp).max())
+            err = np.abs(gnp - want)
+            raw = np.linalg.norm(err) / den if den > 0 else float(np.abs(gnp).max())
+            # fp16 stores results below 2^-14 on a fixed 2^-24 grid: a short user under a 1/N scale with N in the hundreds
+            # lands there (seed 63 case 120: 51 rows, N = 493, |out| ~ 4e-5), and the rounding of the STORE is then a property
+            # of the format, not of the kernel.  Same rule as tests/test_attention_gpu.py: one quantum of slack per element.
+            rel = np.linalg.norm(np.maximum(err - FP16_QUANTUM, 0.0)) / den if (dtype == torch.float16 and den > 0) else raw
             worst[str(dtype)[6:]] = max(worst[str(dtype)[6:]], rel)
+            if dtype == torch.float16:
+                worst["float16 (before the subnormal quantum)"] = max(worst["float16 (before the subnormal quantum)"], raw)
             if not np.isfinite(gnp).all() or rel > GATE[dtype]:
                 fails += 1
-                print("FAIL", desc, f"-> {name}: rel Frobenius {rel:.3e} (gate {GATE[dtype]}), finite={bool(np.isfinite(gnp).all())}, targets={with_t}")
+                print("FAIL", desc, f"-> {name}: rel Frobenius {rel:.3e} (raw {raw:.3e}, gate {GATE[dtype]}), finite={bool(np.isfinite(gnp).all())}, targets={with_t}")
     print(f"{a.cases} cases, {fails} failures; worst relative Frobenius error by dtype: " + ", ".join(f"{k} {v:.2e}" for k, v in sorted(worst.items())))
     for kname, n in sorted(kernels.items(), key=lambda kv: -kv[1]):
         print(f"  {n:4d}  {kname}")
