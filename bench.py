@@ -667,6 +667,9 @@ def projection_section(rows, D, device):
         "out_dgrad": (lambda: torch.mm(g_out, w_out.t()), 2.0 * rows * 3 * D * D),
         "out_wgrad": (lambda: weight_grad_mm(y3, g_out), 2.0 * rows * 3 * D * D),
     })
+    k512_ok = _launch.linear_k512_supported(g_out, 3 * D)
+    if k512_ok:
+        cases["out_dgrad_k512"] = (lambda: _launch.linear_k512(g_out, w_out), 2.0 * rows * 3 * D * D)
     hbm_bytes = {"uvqk_fwd_fused": rows * (D + 4 * D) * 2.0, "uvqk_fwd_fused_with_normed": rows * (2 * D + 4 * D) * 2.0,
                  "bias_grad": rows * 4 * D * 2.0}
     if _launch.column_sum_supported(g_uvqk):
@@ -689,6 +692,10 @@ def projection_section(rows, D, device):
             res[name].update(algorithmic_GBps=round(gbps, 0), hbm_frac=round(gbps / HBM_PEAK_GBPS, 3))
         if name.startswith("uvqk_fwd_fused"):
             res[name]["kernel"] = "hstu_ln_linear_fwd_kernel (LayerNorm inside; what the product runs)"
+        if name == "out_dgrad_k512":
+            res[name]["kernel"] = "hstu_ln_linear_fwd_kernel without the LayerNorm (hstu_linear_k512; what the product runs)"
+        if name == "out_dgrad":
+            res[name]["kernel"] = "hipBLASLt mm (comparator: the product runs out_dgrad_k512 at this shape)" if k512_ok else "hipBLASLt mm"
         if name == "uvqk_fwd":
             res[name]["kernel"] = "hipBLASLt linear (comparator: the product runs uvqk_fwd_fused at this shape)" if fused_ok else "hipBLASLt linear"
     return res

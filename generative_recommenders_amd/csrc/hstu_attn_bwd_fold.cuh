@@ -76,6 +76,19 @@
 #ifndef FOLD_DS_FMA
 #define FOLD_DS_FMA 1          // dS' = dP (sg + P' (1 - sg)) instead of dP sg (1 + x (1 - sg)): one packed instruction per element pair less
 #endif
+#ifndef FOLD_SETPRIO
+#define FOLD_SETPRIO 0     // (experiment) wave priority by phase of a pair: 1 MFMA streams high; 2 element-wise block high; 4 graded, later phase first
+#endif
+#if FOLD_SETPRIO
+#define FOLD_PRIO(mfma_hi, elem_hi, graded)                                                                   \
+  do {                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    __builtin_amdgcn_s_setprio((FOLD_SETPRIO & 1) ? (mfma_hi) : (FOLD_SETPRIO & 2) ? (elem_hi) : (graded));   \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
+#else
+#define FOLD_PRIO(mfma_hi, elem_hi, graded) do {} while (0)
+#endif
 #ifndef FOLD_PERSIST
 #define FOLD_PERSIST 2     // 0: one workgroup per (user, head); 1: one workgroup per CU walks the problems; 2: and issues the
 #endif                     // next problem's K/V tiles of the slots its own tail does not use
@@ -229,6 +242,7 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
   // barriers: left alone, hipcc emits read, read, wait, MFMA per item into the same registers, i.e. one full LDS
   // latency per MFMA, and the pair is latency bound whoever shares the SIMD.
   static_assert(DQK == DV, "interleaved S / dP stream");
+  FOLD_PRIO(3, 0, 1);
   {
     constexpr int NM = 2 * C::KGQ, AHEAD = FOLD_SDP_AHEAD;
     Frag fa[AHEAD + 1], fb[AHEAD + 1];
@@ -260,6 +274,7 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
     }
   }
   HSTU_MARK(11);
+  FOLD_PRIO(0, 3, 2);
   int t_k32 = 0;
   if constexpr (BX::on) {
     if (bx.bc.small) t_k32 = bx.bc.t32_at(key);
@@ -349,6 +364,7 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
   elem(0);
   elem(1);
   HSTU_MARK(12);
+  FOLD_PRIO(3, 0, 3);
   // dV_w^T[dv][key] += dO_i^T[dv][q] P'[q][key]   and   dK_w^T[d][key] += Q_i^T[d][q] dS'[q][key]:
   // one stream of 16 MFMAs alternating between the dV and dK accumulators, A fragments (transposed LDS reads of
   // the dO / Q tile) requested AHEAD items before their MFMA, order pinned as above
@@ -371,6 +387,7 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  FOLD_PRIO(0, 0, 0);
   // publish dS' as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3) = chunk hf + 2 rq
   // (the slot's first 256 bytes may be the landing place of this wave's L2-touch DMA, issued at the top of the step: landed first)
   if (FOLD_L2_TOUCH && !BX::on && DQK == 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

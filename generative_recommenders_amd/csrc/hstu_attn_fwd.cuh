@@ -48,6 +48,19 @@ constexpr int kFwdThreads = 256;
 #ifndef FWD_DMA_FAST
 #define FWD_DMA_FAST 1      // K/V LDS-DMA source addresses: uniform base + 32-bit lane offset from a per-lane plan (3 VALU per chunk)
 #endif
+#ifndef FWD_SETPRIO
+#define FWD_SETPRIO 0       // (experiment) wave priority by phase of a key tile: 1 MFMA chains high; 2 element-wise block high; 4 graded, later phase first; +8: with scheduling barriers
+#endif
+#if FWD_SETPRIO
+#define FWD_PRIO(mfma_hi, elem_hi, graded)                                                                  \
+  do {                                                                                                      \
+    if (FWD_SETPRIO & 8) __builtin_amdgcn_sched_barrier(0);                                                 \
+    __builtin_amdgcn_s_setprio((FWD_SETPRIO & 1) ? (mfma_hi) : (FWD_SETPRIO & 2) ? (elem_hi) : (graded));   \
+    if (FWD_SETPRIO & 8) __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define FWD_PRIO(mfma_hi, elem_hi, graded) do {} while (0)
+#endif
 #ifndef FWD_EPI_FREE
 #define FWD_EPI_FREE 1      // epilogue without a workgroup barrier: output tiles are parked in the ring slots that are dead after the last step
 #endif
@@ -501,6 +514,7 @@ __global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void
       // strictly below its rows: no mask at all (rows past the sequence end are zero-filled: silu(0) = 0).
       const int mode = tile_full ? 0 : (mc.simple ? (diag_fast ? 4 : 1) : (mc.ctx == 0 ? 3 : 2));
       f32x16 s;
+      FWD_PRIO(3, 0, 1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
@@ -518,6 +532,7 @@ __global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void
       }
       HSTU_MID_STEP();      // every wave has read the K tile (its LDS reads retired before the MFMAs issued): that half of the slot is free
       HSTU_MARK(11);
+      FWD_PRIO(0, 3, 2);
       Frag pb[2];
       [[maybe_unused]] Frag pbl[2];   // PRECISE: the remainders of P' after its rounding to the I/O dtype
 #pragma unroll
@@ -609,6 +624,7 @@ __global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void
         }
       }
       HSTU_MARK(12);
+      FWD_PRIO(3, 0, 3);
 #pragma unroll
       for (int d = 0; d < C::DB; ++d) {
 #pragma unroll
@@ -618,6 +634,7 @@ __global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void
           if constexpr (PRECISE) oacc[d] = E::mma(a, pbl[ks], oacc[d]);
         }
       }
+      FWD_PRIO(0, 0, 0);
     } else {
       HSTU_MID_STEP();
     }

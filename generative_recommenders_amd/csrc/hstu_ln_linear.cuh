@@ -149,7 +149,8 @@ HSTU_DEV const char* lnl_row_ptr(const LnLinearArgs& g, int64_t row0, int lane) 
 }
 
 // TAB16: the LayerNorm tables sit in LDS in the I/O type (the two-workgroup arrangement's 80 KiB budget) instead of fp32
-template <typename T, bool NORMED, bool TAB16 = false>
+// LN = false: the rows as they are (the plain K = 512 product of hstu_linear_k512: no statistics, no affine)
+template <typename T, bool NORMED, bool TAB16 = false, bool LN = true>
 HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t row0, const float* gam, const float* bet, int lane,
                             u32x4 (&xf)[kLnlKS], bool preloaded, char* stage, bool x_lines = LNL_X_LINES) {
   using DT = LnlDot<T>;
@@ -194,7 +195,7 @@ HSTU_DEV void lnl_load_rows(const LnLinearArgs& g, int64_t row0, const float* ga
 #pragma unroll
     for (int ks = 0; ks < kLnlKS; ++ks) xf[ks] = gload16(xp + ks * 32);
   }
-  if (LNL_ABLATE & 8) return;
+  if (!LN || (LNL_ABLATE & 8)) return;
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int ks = 0; ks < kLnlKS; ++ks)
@@ -323,9 +324,10 @@ HSTU_DEV LnlPacked lnl_pack_tile(const f32x16& acc, char* stage, int lane) {
 }
 
 // NORMED: the instantiation that also writes the normalised rows (its extra addressing would cost the other one 8 spilled registers)
-template <typename T, bool NORMED>
+template <typename T, bool NORMED, bool LN = true>
 __global__ __launch_bounds__(kLnlThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
+  static_assert(LN || !NORMED, "normalised rows only exist with the LayerNorm");
   extern __shared__ __attribute__((aligned(1024))) char lnl_smem[];
   typedef Elem<T> E;
   typedef typename E::Frag Frag;
@@ -336,9 +338,11 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
   float* gam = (float*)(lnl_smem + kLnlRingBytes);
   float* bet = gam + kLnlK;
   float* bia = bet + kLnlK;
-  for (int i = tid; i < kLnlK; i += kLnlThreads) {
-    gam[i] = (float)((const T*)g.ln_w)[i];
-    bet[i] = (float)((const T*)g.ln_b)[i];
+  if constexpr (LN) {
+    for (int i = tid; i < kLnlK; i += kLnlThreads) {
+      gam[i] = (float)((const T*)g.ln_w)[i];
+      bet[i] = (float)((const T*)g.ln_b)[i];
+    }
   }
   for (int i = tid; i < g.n; i += kLnlThreads) bia[i] = g.bias ? (float)((const T*)g.bias)[i] : 0.f;
 
@@ -479,7 +483,7 @@ void hstu_ln_linear_fwd_kernel(const LnLinearArgs g) {
   bool preloaded = false;
   while (left > 0) {
     LNL_MARK(2);
-    lnl_load_rows<T, NORMED>(g, blk * kLnlBlockRows + wave * 32, gam, bet, lane, xf, preloaded, stage);
+    lnl_load_rows<T, NORMED, false, LN>(g, blk * kLnlBlockRows + wave * 32, gam, bet, lane, xf, preloaded, stage);
     LNL_MARK(3);
     const int64_t row = blk * kLnlBlockRows + wave * 32 + (lane >> 2);      // the lane's rows at store time: row, row + 16
     const bool live = !(LNL_ABLATE & 1) || g.eps == 12345.f;
@@ -535,7 +539,7 @@ static int launch_ln_linear(const LnLinearArgs& g, hipStream_t st) {
 #ifdef LNL_TRACE
   auto kern = hstu_ln_linear_fwd_kernel<T, false>;
 #else
-  auto kern = g.normed ? hstu_ln_linear_fwd_kernel<T, true> : hstu_ln_linear_fwd_kernel<T, false>;
+  auto kern = !g.ln_w ? hstu_ln_linear_fwd_kernel<T, false, false> : g.normed ? hstu_ln_linear_fwd_kernel<T, true> : hstu_ln_linear_fwd_kernel<T, false>;
 #endif
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "ln_linear_fwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));

@@ -400,6 +400,29 @@ def ln_linear_fwd(x, ln_weight, ln_bias, eps, w_nk, bias, want_normed=False):
     return y, normed, mean, rstd
 
 
+def linear_k512_supported(x, n):
+    """whether hstu_linear_k512 takes (rows, 512) activations (last dimension contiguous, row stride a multiple of 8) and n output columns"""
+    return bool(x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.stride(1) == 1 and
+                x.stride(0) % 8 == 0 and x.stride(0) >= x.shape[1] and x.data_ptr() % 16 == 0 and
+                L.lib().hstu_linear_k512_supported(x.shape[0], x.shape[1], n, L.torch_dtype_code(x.dtype)))
+
+
+def linear_k512(x, w_nk, bias=None):
+    """y = x @ w_nk.T (+ bias) with a contraction length of 512 (csrc/hstu_ln_linear.cuh without the LayerNorm): the output
+    stage's d y = d out . W_out^T, whose (n, k) operand is the layer's ``_output_weight`` as stored."""
+    L.require_gpu_tensor(x, "x")
+    rows, k = x.shape
+    n = w_nk.shape[0]
+    torch._assert(w_nk.shape[1] == k and w_nk.is_contiguous() and w_nk.dtype == x.dtype, "w_nk must be a contiguous (n, k) tensor of x's dtype")
+    torch._assert(x.stride(1) == 1, "x must have a contiguous last dimension")
+    y = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+    pb = None if bias is None else bias.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_linear_k512(x.data_ptr(), x.stride(0), w_nk.data_ptr(), None if pb is None else pb.data_ptr(),
+                                         y.data_ptr(), n, rows, k, n, L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
+    return y
+
+
 def layer_norm_bwd(dy, x, weight, mean, rstd, dresidual=None):
     """``dresidual``: a gradient that reaches x around the norm; added inside the kernel (dx = LN'(dy) + dresidual)."""
     dy, x = dy.contiguous(), x.contiguous()

@@ -270,6 +270,16 @@ class _NormMulFunction(torch.autograd.Function):
         return dattn, du, dw.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None, None
 
 
+def _out_dgrad(dout, Wo):
+    """d y = d out . W_out^T (reference: dx = torch.mm(dz, w.t()), ops/triton/triton_addmm.py:302-315).  The contraction runs over
+    the embedding dim; at 512 the hand-written kernel takes it (W_out as stored IS its K-contiguous operand), else hipBLASLt.
+    ``HSTU_OUT_DGRAD_KERNEL=0``: always hipBLASLt (A/B runs)."""
+    if (os.environ.get("HSTU_OUT_DGRAD_KERNEL", "1") != "0" and Wo.is_contiguous() and Wo.dtype == dout.dtype
+            and _launch.linear_k512_supported(dout, Wo.shape[0])):
+        return _launch.linear_k512(dout, Wo)
+    return torch.mm(dout, Wo.t())
+
+
 class _ComputeOutputFunction(torch.autograd.Function):
     """out = x + [u, attn, u*Norm(attn)] @ W_o as ONE node (HSTUComputeOutputFunction,
     triton_hstu_linear.py:1137-1308): y is recomputed in backward unless asked otherwise."""
@@ -303,7 +313,7 @@ class _ComputeOutputFunction(torch.autograd.Function):
             y = ctx.saved_tensors[7]
         dout = dout.contiguous()
         nw_dtype, nb_dtype, wo_dtype = ctx.param_dtypes
-        dy = torch.mm(dout, Wo.t())
+        dy = _out_dgrad(dout, Wo)
         dWo = weight_grad_mm(y, dout, out_dtype=wo_dtype)
         dattn, du, dnw, dnb = _launch.norm_mul_bwd(dy, attn, u, nw, nb, mean, rstd, H, Ld, gn, cat, p_drop, seed)
         return (dattn, du, dout, dnw.to(nw_dtype), dnb.to(nb_dtype), dWo, None, None, None, None, None, None, None,
@@ -480,7 +490,7 @@ class _STULayerFunction(torch.autograd.Function):
         dt = ctx.param_dtypes
         # ---- output stage (dout is also the gradient of the residual)
         dout = dout.contiguous()
-        dy = torch.mm(dout, Wo.t())
+        dy = _out_dgrad(dout, Wo)
         dWo = weight_grad_mm(y, dout, out_dtype=dt[6])
         del y
         duvqk = torch.empty_like(uvqk)

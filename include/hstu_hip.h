@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 10
+#define HSTU_ABI_VERSION 11
 
 enum {
   HSTU_OK = 0,
@@ -232,6 +232,14 @@ int hstu_ln_linear_fwd_supported(int64_t rows, int32_t k, int32_t n, int dtype);
 int hstu_ln_linear_fwd(const void* x, int64_t ldx, const void* ln_weight, const void* ln_bias, float eps,
                        const void* w_nk, const void* bias, void* y, int64_t ldy, void* normed, int64_t ldn,
                        float* mean, float* rstd, int64_t rows, int32_t k, int32_t n, int dtype, void* stream);
+/* ABI v11: y = x . W^T (+ bias) for a contraction length of 512 -- the same kernel without the LayerNorm (rows of x in
+ * registers, W streamed through LDS).  Used for d y = d out . W_out^T in the output stage's backward, where k is the
+ * embedding dim and the (n, k) K-contiguous operand is the reference's (3 H d, D) `_output_weight` as stored
+ * (dx = torch.mm(dz, w.t()): ops/triton/triton_addmm.py:302-315; caller ops/hstu_compute.py:92-136).  Same shape rule
+ * and alignment as hstu_ln_linear_fwd; bias may be NULL. */
+int hstu_linear_k512_supported(int64_t rows, int32_t k, int32_t n, int dtype);
+int hstu_linear_k512(const void* x, int64_t ldx, const void* w_nk, const void* bias, void* y, int64_t ldy,
+                     int64_t rows, int32_t k, int32_t n, int dtype, void* stream);
 int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight,
                         const float* mean, const float* rstd, void* dx,
                         float* dweight, float* dbias, float* partial_ws,

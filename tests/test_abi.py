@@ -45,7 +45,7 @@ def test_ctypes_signature_table_covers_header():
 
 def test_abi_version_and_error_string(lib):
     from generative_recommenders_amd import _lib as L
-    assert lib.hstu_abi_version() == L.ABI_VERSION == 10
+    assert lib.hstu_abi_version() == L.ABI_VERSION == 11
     assert isinstance(lib.hstu_last_error(), bytes)
 
 
@@ -121,6 +121,22 @@ def test_ln_linear_shape_rule_and_validation_without_gpu(lib):
     assert call(ldx=516) == -1 and b"multiples of 8" in lib.hstu_last_error()
     assert call(y=a + 8) == -1 and b"16-byte aligned" in lib.hstu_last_error()
     assert call(normed=a, ldn=100) == -1 and b"leading dimension" in lib.hstu_last_error()
+
+
+def test_linear_k512_shape_rule_and_validation_without_gpu(lib):
+    """hstu_linear_k512 (ABI v11): the fused kernel's shape rule, and its argument checks -- all before any launch"""
+    BF16, F32 = 0, 2
+    sup = lib.hstu_linear_k512_supported
+    assert sup(1000, 512, 1536, BF16) == 1 and sup(1000, 512, 1536, F32) == 0 and sup(1000, 256, 1536, BF16) == 0 and sup(5, 512, 1000, BF16) == 0
+    buf = (C.c_char * 4096)()
+    a = (C.addressof(buf) + 15) & ~15
+    call = lambda x=a, ldx=512, w=a, y=a, ldy=1536, rows=4, k=512, n=1536, dt=BF16: lib.hstu_linear_k512(x, ldx, w, None, y, ldy, rows, k, n, dt, None)
+    assert call(rows=0) == 0
+    assert call(w=None) == -1 and b"NULL" in lib.hstu_last_error()
+    assert call(k=1536, n=512) == -1 and b"k == 512" in lib.hstu_last_error()
+    assert call(ldy=1528) == -1 and b"leading dimension" in lib.hstu_last_error()
+    assert call(ldx=516) == -1 and b"multiples of 8" in lib.hstu_last_error()
+    assert call(x=a + 8) == -1 and b"16-byte aligned" in lib.hstu_last_error()
 
 
 def test_ops_fail_loudly_on_cpu_tensors():

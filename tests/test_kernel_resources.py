@@ -80,6 +80,8 @@ def test_no_kernel_spills_or_uses_scratch():
     # The fused LayerNorm + projection kernel's instantiation that also writes the normalised rows (backward's recompute): 8
     # registers of its extra addressing live in scratch across the row prologue; the forward's instantiation may not spill.
     bounded.update({"hstu_ln_linear_fwd_kernelIDF16bLb1E": 8, "hstu_ln_linear_fwd_kernelIDF16_Lb1E": 8})
+    # ... and the instantiation without the LayerNorm (hstu_linear_k512) keeps 2 outside the tile loop
+    bounded.update({"hstu_ln_linear_fwd_kernelIDF16bLb0ELb0E": 2, "hstu_ln_linear_fwd_kernelIDF16_Lb0ELb0E": 2})
     bad = {k: v for k, v in ks.items() if (v["spill"] or v["scratch"]) and "hstu" in k and not any(a in k for a in accepted)
            and not any(b in k and v["spill"] <= n for b, n in bounded.items())}
     assert not bad, f"kernels with register spills / scratch: {bad}"
@@ -95,5 +97,5 @@ def test_hot_kernels_stay_under_their_occupancy_limits():
     assert fwd[0]["vgpr"] <= 168, fwd            # 3 waves per SIMD (512 / 3, allocation granule 8)
     assert fold[0]["vgpr"] <= 256, fold          # 2 waves per SIMD
     assert fold64[0]["vgpr"] <= 256, fold64
-    lnl = find("hstu_ln_linear_fwd_kernelIDF16bLb0E")                  # two waves per SIMD, the rows of x in 128 of the registers
+    lnl = find("hstu_ln_linear_fwd_kernelIDF16bLb0ELb1E")                # two waves per SIMD, the rows of x in 128 of the registers
     assert len(lnl) == 1 and lnl[0]["vgpr"] <= 256 and lnl[0]["spill"] == 0, lnl

@@ -206,3 +206,86 @@ def test_public_uvqk_op_runs_the_fused_kernel_forward_backward_and_row_results_d
         part = hstu_compute_uqvk(x0[sub].to(DEV), nw0.to(DEV), nb0.to(DEV), 1e-6, H, A, Hd, W0.to(DEV), b0.to(DEV))
         for f, p in zip(full, part):
             assert torch.equal(f[sub.to(DEV)], p)
+
+
+# ---- hstu_linear_k512 (ABI v11): the same kernel without the LayerNorm -- d y = d out . W_out^T of the output stage's backward
+
+
+@pytest.mark.parametrize("rows,n,dtype", [(1, 32, torch.bfloat16), (255, 1536, torch.float16), (257, 96, torch.bfloat16),
+                                          (4099, 1536, torch.bfloat16), (70000, 1536, torch.bfloat16), (66000, 512, torch.float16)])
+def test_linear_k512_vs_fp64_product(rows, n, dtype):
+    """y = x W^T on the same 16-bit inputs in exact arithmetic (what the reference's dx = torch.mm(dz, w.t()) computes,
+    ops/triton/triton_addmm.py:302-315): one rounding of y to the I/O dtype -- relative Frobenius <= 2.8e-3 bf16 / 3.2e-4 fp16 --
+    and bit-identical from run to run; with and without a bias"""
+    from generative_recommenders_amd.ops import _launch
+
+    g = torch.Generator().manual_seed(rows + n)
+    x = torch.randn(rows, 512, generator=g).to(dtype)
+    w = (torch.randn(n, 512, generator=g) / 512**0.5).to(dtype)          # (n, k): `_output_weight` as stored
+    b = (0.1 * torch.randn(n, generator=g)).to(dtype)
+    xd, wd = x.to(DEV), w.to(DEV)
+    assert _launch.linear_k512_supported(xd, n)
+    y = _launch.linear_k512(xd, wd)
+    yb = _launch.linear_k512(xd, wd, b.to(DEV))
+    again = _launch.linear_k512(xd, wd)
+    torch.cuda.synchronize()
+    ref = x.double().numpy() @ w.double().numpy().T
+    m = record_parity("linear_k512.y", y.double().cpu().numpy(), ref, str(dtype).replace("torch.", ""))
+    assert m["rel_fro"] <= GATE[dtype], m
+    assert _rel(yb, ref + b.double().numpy()) <= GATE[dtype]
+    assert torch.equal(y, again) and torch.isfinite(y).all()
+
+
+def test_linear_k512_strided_rows_and_refusals():
+    """rows taken from a wider buffer (row stride 1024), and what the kernel does not take"""
+    from generative_recommenders_amd.ops import _launch
+
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn(3001, 1024, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(1536, 512, generator=g) / 512**0.5).to(torch.bfloat16).to(DEV)
+    x = wide[:, 256:768]
+    assert _launch.linear_k512_supported(x, 1536)
+    assert torch.equal(_launch.linear_k512(x, w), _launch.linear_k512(x.contiguous(), w))
+    assert not _launch.linear_k512_supported(wide[:, 4:516], 1536)                      # 8-byte aligned rows only
+    assert not _launch.linear_k512_supported(wide[:, :256], 1536)                       # k != 512
+    assert not _launch.linear_k512_supported(x.float(), 1536) and not _launch.linear_k512_supported(x, 1000)
+    with pytest.raises(RuntimeError, match="k == 512"):
+        _launch.linear_k512(wide[:, :256], w[:, :256].contiguous())
+
+
+def test_output_stage_dgrad_kernel_against_hipblaslt(monkeypatch):
+    """gradients of one STU layer with d y from hstu_linear_k512 (default) against the same layer with torch.mm
+    (HSTU_OUT_DGRAD_KERNEL=0): same operands, same single rounding of d y -- summation order at most"""
+    from generative_recommenders_amd.modules.stu import STULayer, STULayerConfig
+
+    from generative_recommenders_amd.ops import _launch
+
+    calls = []
+    real = _launch.linear_k512
+    monkeypatch.setattr(_launch, "linear_k512", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(env):
+        monkeypatch.setenv("HSTU_OUT_DGRAD_KERNEL", env)
+        torch.manual_seed(0)
+        layer = STULayer(STULayerConfig(embedding_dim=512, num_heads=4, hidden_dim=128, attention_dim=128, output_dropout_ratio=0.0,
+                                        use_group_norm=True)).to(DEV)
+        g = torch.Generator().manual_seed(1)
+        lengths = torch.tensor([200, 13, 0, 177, 200], dtype=torch.int64)
+        off = torch.zeros(6, dtype=torch.int64)
+        off[1:] = torch.cumsum(lengths, 0)
+        x = torch.randn(int(off[-1]), 512, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+        gy = torch.randn(int(off[-1]), 512, generator=g).to(torch.bfloat16).to(DEV)
+        layer(x=x, x_lengths=lengths.to(DEV), x_offsets=off.to(DEV), max_seq_len=200, num_targets=None).backward(gy)
+        torch.cuda.synchronize()
+        return {"dx": x.grad.clone(), **{n: p.grad.clone() for n, p in layer.named_parameters()}}
+
+    a = run("1")
+    assert len(calls) == 1, "the output stage's backward did not go through hstu_linear_k512"
+    b = run("0")
+    assert len(calls) == 1, "HSTU_OUT_DGRAD_KERNEL=0 still ran the kernel"
+    for name in a:
+        ra = a[name].double().cpu().numpy()
+        rb = b[name].double().cpu().numpy()
+        rel = float(np.linalg.norm(ra - rb) / max(np.linalg.norm(rb), 1e-30))
+        assert rel <= 3e-3, (name, rel)
+    # (at this shape the two are in fact bit-identical: both accumulate k in ascending 16-element MFMA steps in fp32 and round once)

@@ -99,5 +99,6 @@ def test_bench_projection_section_calls_the_products_gemms():
     # (embedding dim 256: the fused LayerNorm + projection kernel does not take it, so its two entries are absent here)
     assert set(res) == {"uvqk_fwd", "uvqk_dgrad", "uvqk_wgrad", "out_fwd", "out_dgrad", "out_wgrad", "bias_grad"}
     res512 = bench.projection_section(2048, 512, torch.device(DEV))
-    assert {"uvqk_fwd_fused", "uvqk_fwd_fused_with_normed"} <= set(res512) and res512["uvqk_fwd_fused"]["us"] > 0
+    assert {"uvqk_fwd_fused", "uvqk_fwd_fused_with_normed", "out_dgrad_k512"} <= set(res512) and res512["uvqk_fwd_fused"]["us"] > 0
+    assert res512["out_dgrad_k512"]["tflops"] > 0
     assert all(v["tflops"] > 0 for k, v in res.items() if k != "bias_grad") and res["bias_grad"]["algorithmic_GBps"] > 0
