@@ -89,6 +89,9 @@
 #else
 #define FOLD_PRIO(mfma_hi, elem_hi, graded) do {} while (0)
 #endif
+#ifndef FOLD_STAGGER
+#define FOLD_STAGGER 0     // (experiment) persistent workgroups start out of phase: ((blockIdx >> 3) & 3) * FOLD_STAGGER sleeps of 127 x 64 clocks
+#endif
 #ifndef FOLD_PERSIST
 #define FOLD_PERSIST 2     // 0: one workgroup per (user, head); 1: one workgroup per CU walks the problems; 2: and issues the
 #endif                     // next problem's K/V tiles of the slots its own tail does not use
@@ -1017,6 +1020,8 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   const int total = bp.fwd.batch * bp.fwd.heads;
   if (FOLD_PERSIST) {
     int pre_lo = 7;
+    if (FOLD_STAGGER)
+      for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * FOLD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
     for (int uh = blockIdx.x; uh < total; uh += gridDim.x) {
       int uh_l = uh;
       asm volatile("" : "+s"(uh_l));     // nothing of problem i+1 is hoisted into problem i
