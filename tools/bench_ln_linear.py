@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--n", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--fused-only", action="store_true", help="time the fused kernel only (variant libraries: HSTU_HIP_LIBRARY)")
+    ap.add_argument("--k512", action="store_true", help="the kernel without its LayerNorm (hstu_linear_k512) against torch.mm at the output "
+                    "stage's data-gradient shape: d y = d out . W_out^T, rows x 512 -> n (default n for this mode: 1536)")
     a = ap.parse_args()
     dev, dt, k = "cuda", torch.bfloat16, 512
     g = torch.Generator(device=dev).manual_seed(0)
@@ -38,7 +40,21 @@ def main():
     lb = (0.1 * torch.randn(k, device=dev, generator=g)).to(dt)
     w_nk = (torch.randn(a.n, k, device=dev, generator=g) / k**0.5).to(dt)
     b = (0.1 * torch.randn(a.n, device=dev, generator=g)).to(dt)
+    if a.k512 and a.n == 2048:
+        a.n = 1536
     flops = 2.0 * a.rows * k * a.n
+    if a.k512:
+        w_out = (torch.randn(a.n, k, device=dev, generator=g) / k**0.5).to(dt)     # `_output_weight` as stored: (3 H d, D)
+        res = {"rows": a.rows, "k": k, "n": a.n, "dtype": "bf16", "what": "d y = d out . W_out^T"}
+        for _ in range(40):
+            _launch.linear_k512(x, w_out)
+        res["hipblaslt_mm_us"] = timed(lambda: torch.mm(x, w_out.t()), a.iters)
+        res["linear_k512_us"] = timed(lambda: _launch.linear_k512(x, w_out), a.iters)
+        for key in ("hipblaslt_mm_us", "linear_k512_us"):
+            res[key.replace("_us", "_tflops")] = round(flops / res[key] / 1e6, 1)
+        res["bit_identical"] = bool(torch.equal(_launch.linear_k512(x, w_out), torch.mm(x, w_out.t())))
+        print(json.dumps({k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in res.items()}))
+        return
 
     def unfused():
         nx, _, _ = _launch.layer_norm_fwd(x, lw, lb, 1e-6)
