@@ -17,6 +17,10 @@
                        // SiLU fwd 81 -> 62 us, the others -1..-3 %, layer step unchanged); loads mixed (norm_mul bwd +6 %): off.  profiles/r04_norm_nt.txt
 #endif
 
+#ifndef NORM_FAST_SIGMOID
+#define NORM_FAST_SIGMOID 1
+#endif
+
 namespace hstu {
 // narrow / wide instances of every kernel and launcher (norm_kernels.inc)
 namespace nw1 {
@@ -92,6 +96,35 @@ int hstu_layer_norm_bwd_residual(const void* dy, const void* x, const void* weig
   DISPATCH_DTYPE(dtype, NW(wd, ln_bwd<bf16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, dres, st)),
                  NW(wd, ln_bwd<f16_t>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, dres, st)),
                  NW(wd, ln_bwd<float>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, dres, st)));
+}
+
+// y = x * sigmoid(LayerNorm(x)): the gate in front of the preprocessors' and DlrmHSTU's MLPs (SwishLayerNorm)
+int hstu_swish_layer_norm_fwd(const void* x, const void* weight, const void* bias, void* y, float* mean, float* rstd,
+                              int64_t rows, int32_t dim, float eps, int dtype, void* stream) {
+  if (rows == 0) return HSTU_OK;
+  if (!x || !weight || !bias || !y) return set_error(HSTU_EINVAL, "swish_layer_norm_fwd: NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  const bool wd = norm_wide(dim, x, y, weight, dtype == HSTU_DTYPE_F32 ? 4 : 2);
+  DISPATCH_DTYPE(dtype, NW(wd, ln_fwd<bf16_t, true>(x, weight, bias, y, mean, rstd, rows, dim, eps, st)),
+                 NW(wd, ln_fwd<f16_t, true>(x, weight, bias, y, mean, rstd, rows, dim, eps, st)),
+                 NW(wd, ln_fwd<float, true>(x, weight, bias, y, mean, rstd, rows, dim, eps, st)));
+}
+
+int hstu_swish_layer_norm_bwd(const void* dy, const void* x, const void* weight, const void* bias, const float* mean,
+                              const float* rstd, void* dx, float* dweight, float* dbias, float* partial_ws, int64_t rows,
+                              int32_t dim, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!dweight || !dbias) return set_error(HSTU_EINVAL, "swish_layer_norm_bwd: dweight/dbias are required");
+  if (rows == 0) {
+    (void)hipMemsetAsync(dweight, 0, dim * sizeof(float), st);
+    (void)hipMemsetAsync(dbias, 0, dim * sizeof(float), st);
+    return HSTU_OK;
+  }
+  if (!dy || !x || !weight || !bias || !mean || !rstd || !dx || !partial_ws) return set_error(HSTU_EINVAL, "swish_layer_norm_bwd: NULL tensor");
+  const bool wd = norm_wide(dim, dy, x, dx, dtype == HSTU_DTYPE_F32 ? 4 : 2);
+  DISPATCH_DTYPE(dtype, NW(wd, ln_bwd<bf16_t, true>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, nullptr, st, bias)),
+                 NW(wd, ln_bwd<f16_t, true>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, nullptr, st, bias)),
+                 NW(wd, ln_bwd<float, true>(dy, x, weight, mean, rstd, dx, dweight, dbias, partial_ws, rows, dim, nullptr, st, bias)));
 }
 
 static int drop_ratio_ok(float r, const char* who) {

@@ -373,6 +373,36 @@ def layer_norm_fwd(x, weight, bias, eps):
     return y, mean, rstd
 
 
+def swish_layer_norm_fwd(x, weight, bias, eps):
+    """y = x * sigmoid(LayerNorm(x)) (hstu_swish_layer_norm_fwd): returns (y, mean, rstd)"""
+    L.require_gpu_tensor(x, "x")
+    x = x.contiguous()
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    mean, rstd = _f32(rows, x.device), _f32(rows, x.device)
+    w, b = weight.to(x.dtype).contiguous(), bias.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_swish_layer_norm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                  rstd.data_ptr(), rows, dim, float(eps), L.torch_dtype_code(x.dtype),
+                                                  L.current_stream_ptr(x.device)))
+    return y, mean, rstd
+
+
+def swish_layer_norm_bwd(dy, x, weight, bias, mean, rstd):
+    """dx, dweight (fp32), dbias (fp32) of swish_layer_norm_fwd"""
+    dy, x = dy.contiguous(), x.contiguous()
+    rows, dim = x.shape
+    dx = torch.empty_like(x)
+    dw, db = _f32(dim, x.device), _f32(dim, x.device)
+    ws = torch.empty(L.lib().hstu_norm_bwd_workspace_bytes(rows, dim), dtype=torch.uint8, device=x.device)
+    w, b = weight.to(x.dtype).contiguous(), bias.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device):
+        L.check(L.lib().hstu_swish_layer_norm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                                                  rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                                  rows, dim, L.torch_dtype_code(x.dtype), L.current_stream_ptr(x.device)))
+    return dx, dw, db
+
+
 def ln_linear_supported(x, n):
     """whether the fused LayerNorm + projection kernel takes (rows, k) activations and n output columns"""
     return bool(x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and

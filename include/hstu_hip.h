@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 11
+#define HSTU_ABI_VERSION 12
 
 enum {
   HSTU_OK = 0,
@@ -232,6 +232,17 @@ int hstu_ln_linear_fwd_supported(int64_t rows, int32_t k, int32_t n, int dtype);
 int hstu_ln_linear_fwd(const void* x, int64_t ldx, const void* ln_weight, const void* ln_bias, float eps,
                        const void* w_nk, const void* bias, void* y, int64_t ldy, void* normed, int64_t ldn,
                        float* mean, float* rstd, int64_t rows, int32_t k, int32_t n, int dtype, void* stream);
+/* ABI v12: y = x * sigmoid(LayerNorm(x)) -- swish_layer_norm (ops/layer_norm.py:79-112; math ops/pytorch/pt_layer_norm.py:41-62;
+ * Triton: ops/triton/triton_layer_norm.py), the gate SwishLayerNorm puts in front of the MLPs of the input preprocessors
+ * (modules/preprocessors.py:160,181), the contextual MLPs (modules/contextualize_mlps.py:63,116) and DlrmHSTU
+ * (modules/dlrm_hstu.py:144,240).  Same contract as hstu_layer_norm_fwd / _bwd: fp32 math, mean / rstd (fp32, per row) are
+ * outputs of the forward (may be NULL) and inputs of the backward, dweight / dbias fp32, partial_ws of
+ * hstu_norm_bwd_workspace_bytes(rows, dim) bytes; rows == 0 zeroes dweight / dbias. */
+int hstu_swish_layer_norm_fwd(const void* x, const void* weight, const void* bias, void* y, float* mean, float* rstd,
+                              int64_t rows, int32_t dim, float eps, int dtype, void* stream);
+int hstu_swish_layer_norm_bwd(const void* dy, const void* x, const void* weight, const void* bias, const float* mean,
+                              const float* rstd, void* dx, float* dweight, float* dbias, float* partial_ws, int64_t rows,
+                              int32_t dim, int dtype, void* stream);
 /* ABI v11: y = x . W^T (+ bias) for a contraction length of 512 -- the same kernel without the LayerNorm (rows of x in
  * registers, W streamed through LDS).  Used for d y = d out . W_out^T in the output stage's backward, where k is the
  * embedding dim and the (n, k) K-contiguous operand is the reference's (3 H d, D) `_output_weight` as stored

@@ -493,6 +493,25 @@ def layer_norm_bwd(dy, x, weight, eps, dtype=np.float64):
     return dx, (dy * xhat).sum(axis=0), dy.sum(axis=0)
 
 
+def swish_layer_norm_fwd(x, weight, bias, eps, dtype=np.float64):
+    """y = x * sigmoid(LayerNorm(x)), math in ``dtype``.  ops/pytorch/pt_layer_norm.py:41-62 (the gate in front of the
+    preprocessors' and DlrmHSTU's MLPs: modules/preprocessors.py:160,181, modules/dlrm_hstu.py:144,240)."""
+    x = x.astype(dtype)
+    z = layer_norm_fwd(x, weight, bias, eps, dtype)
+    return x / (1.0 + np.exp(-z))
+
+
+def swish_layer_norm_bwd(dy, x, weight, bias, eps, dtype=np.float64):
+    """dx, dweight, dbias of :func:`swish_layer_norm_fwd`: with s = sigmoid(z), d z = dy x s (1 - s) goes through the
+    LayerNorm's backward, and dy s reaches x directly."""
+    x = x.astype(dtype)
+    dy = dy.astype(dtype)
+    s = 1.0 / (1.0 + np.exp(-layer_norm_fwd(x, weight, bias, eps, dtype)))
+    dz = dy * x * s * (1.0 - s)
+    dx, dw, db = layer_norm_bwd(dz, x, weight, eps, dtype)
+    return dx + dy * s, dw, db
+
+
 def group_norm_rows(x, weight, bias, eps, num_heads, linear_dim, dtype=np.float64):
     """Per-row, per-head normalisation with one (weight, bias) scalar per head.
 

@@ -41,7 +41,7 @@ from generative_recommenders.ops.jagged_tensors import (  # noqa: E402
     hstu_split_l2_embeddings,
     split_2D_jagged,
 )
-from generative_recommenders.ops.layer_norm import layer_norm  # noqa: E402
+from generative_recommenders.ops.layer_norm import SwishLayerNorm, layer_norm, swish_layer_norm  # noqa: E402
 from generative_recommenders.modules.stu import STULayer, STULayerConfig, STUStack  # noqa: E402
 
 PT = HammerKernel.PYTORCH
@@ -223,6 +223,29 @@ def compute_cases():
                          gn=gn, cat=cat, y=_np(y), gy=_np(gy), dattn=_np(attn.grad), du=_np(u.grad),
                          dx=_np(x.grad), dnw=_np(nw.grad), dnb=_np(nb.grad), dWo=_np(Wo.grad))
     return out
+
+
+def swish_layer_norm_cases():
+    """swish_layer_norm(kernel=PYTORCH) (ops/layer_norm.py:79-112 -> ops/pytorch/pt_layer_norm.py:41-62) forward + autograd, and the
+    SwishLayerNorm module at the width DlrmHSTU uses it (modules/dlrm_hstu.py:144)"""
+    gen = torch.Generator().manual_seed(77)
+    cases = []
+    for rows, dim, shift in [(37, 48, 0.0), (5, 512, 0.0), (64, 200, 3.0), (1, 8, 0.0), (33, 1000, 0.5)]:
+        x = (torch.randn(rows, dim, generator=gen) * (0.5 + torch.rand(rows, 1, generator=gen)) + shift).requires_grad_()
+        w = (1 + 0.2 * torch.randn(dim, generator=gen)).requires_grad_()
+        b = (0.2 * torch.randn(dim, generator=gen)).requires_grad_()
+        y = swish_layer_norm(x, w, b, 1e-5, kernel=PT)
+        gy = torch.randn(y.shape, generator=gen)
+        y.backward(gy)
+        cases.append(dict(x=_np(x), w=_np(w), b=_np(b), eps=1e-5, y=_np(y), gy=_np(gy), dx=_np(x.grad), dw=_np(w.grad), db=_np(b.grad)))
+    m = SwishLayerNorm(512)
+    m.set_hammer_kernel(PT)
+    with torch.no_grad():
+        m.weight.copy_(1 + 0.1 * torch.randn(512, generator=gen))
+        m.bias.copy_(0.1 * torch.randn(512, generator=gen))
+    x = torch.randn(9, 512, generator=gen)
+    cases.append(dict(x=_np(x), w=_np(m.weight), b=_np(m.bias), eps=1e-5, y=_np(m(x)), module=1))
+    return cases
 
 
 def stu_case():
@@ -671,6 +694,7 @@ def main():
         ("attention", attention_cases), ("delta_attention", delta_cases), ("jagged", lambda: jagged_cases()[0]),
         ("jagged_l2", lambda: [jagged_cases()[1]]),
         ("compute", lambda: [dict(name=np.asarray(n), **c) for n, c in compute_cases().items()]),
+        ("swish_layer_norm", swish_layer_norm_cases),
         ("stu", lambda: [stu_case()]), ("research_attention", lambda: [research_case()]), ("position", position_cases),
         ("postprocess", postprocess_cases), ("sampled_softmax", sampled_softmax_cases),
         ("metric_shapes", metric_shape_cases), ("research_layer", research_layer_cases), ("hstu_model", hstu_model_cases),

@@ -118,6 +118,22 @@ def test_layer_norm_matches_reference():
     np.testing.assert_allclose(y, c["y"], rtol=2e-5, atol=2e-6)
 
 
+def test_swish_layer_norm_matches_reference():
+    """oracle (fp64) against the reference's pytorch_swish_layer_norm + autograd (fp32): tests/golden/swish_layer_norm.npz"""
+    cases = load_cases("swish_layer_norm.npz")
+    assert len(cases) == 6
+    for c in cases:
+        eps = float(c["eps"])
+        y = O.swish_layer_norm_fwd(c["x"], c["w"], c["b"], eps)
+        np.testing.assert_allclose(y, c["y"], rtol=3e-5, atol=3e-6)
+        if "gy" in c:
+            dx, dw, db = O.swish_layer_norm_bwd(c["gy"], c["x"], c["w"], c["b"], eps)
+            scale = max(1.0, float(np.abs(c["dx"]).max()))
+            np.testing.assert_allclose(dx, c["dx"], rtol=2e-4, atol=2e-5 * scale)
+            np.testing.assert_allclose(dw, c["dw"], rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(c["dw"]).max())))
+            np.testing.assert_allclose(db, c["db"], rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(c["db"]).max())))
+
+
 def test_uvqk_matches_reference():
     c = _compute("uvqk")
     u, q, k, v = O.hstu_compute_uqvk(c["x"], c["nw"], c["nb"], 1e-6, int(c["H"]), int(c["A"]), int(c["Hd"]),

@@ -1,0 +1,105 @@
+"""GPU parity of swish_layer_norm (y = x * sigmoid(LayerNorm(x)); C entries hstu_swish_layer_norm_fwd / _bwd, ABI v12) against
+the reference-minted fixture (tests/golden/swish_layer_norm.npz: the reference's pytorch_swish_layer_norm + autograd, fp32) and
+against the fp64 oracle (oracle/hstu_oracle.py::swish_layer_norm_fwd / _bwd) on 16-bit inputs.
+
+Tolerances: fp32 I/O -- the kernel's math is fp32 like the reference's: 2e-5 relative to the tensor's scale.  16-bit I/O --
+the oracle is exact arithmetic on the same 16-bit inputs, the kernel rounds y / dx once: relative Frobenius <= 2.8e-3 bf16 /
+3.5e-4 fp16; dweight / dbias are fp32 sums over the rows: 1e-4 of their scale."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_cases, record_parity
+from oracle import hstu_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GATE = {torch.bfloat16: 2.8e-3, torch.float16: 3.5e-4, torch.float32: 2e-6}
+
+
+def _rel(got, ref):
+    g = got.detach().double().cpu().numpy()
+    return float(np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+def test_swish_layer_norm_against_the_reference_fixture():
+    from generative_recommenders_amd.ops.layer_norm import SwishLayerNorm, swish_layer_norm
+
+    for c in load_cases("swish_layer_norm.npz"):
+        x = torch.from_numpy(c["x"]).to(DEV).requires_grad_()
+        w = torch.from_numpy(c["w"]).to(DEV).requires_grad_()
+        b = torch.from_numpy(c["b"]).to(DEV).requires_grad_()
+        eps = float(c["eps"])
+        if "module" in c:
+            m = SwishLayerNorm(x.shape[1], eps=eps).to(DEV)
+            with torch.no_grad():
+                m.weight.copy_(w)
+                m.bias.copy_(b)
+            y = m(x)
+            np.testing.assert_allclose(y.detach().cpu().numpy(), c["y"], rtol=2e-5, atol=2e-6)
+            assert set(dict(m.named_parameters())) == {"weight", "bias"}
+            continue
+        y = swish_layer_norm(x, w, b, eps)
+        y.backward(torch.from_numpy(c["gy"]).to(DEV))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), c["y"], rtol=2e-5, atol=2e-6)
+        for got, key in ((x.grad, "dx"), (w.grad, "dw"), (b.grad, "db")):
+            scale = max(1.0, float(np.abs(c[key]).max()))
+            np.testing.assert_allclose(got.cpu().numpy(), c[key], rtol=2e-4, atol=2e-5 * scale, err_msg=key)
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 8), (7, 512), (4099, 512), (70001, 256), (300, 1024), (33, 4096), (129, 200), (5, 37), (64, 1000)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_swish_layer_norm_vs_oracle(rows, dim, dtype):
+    """rows of one and two register chunks, the wide instance (> 1024), widths without 16-byte alignment (scalar path), more
+    rows than resident waves; forward and backward"""
+    from generative_recommenders_amd.ops import _launch
+
+    g = torch.Generator().manual_seed(rows * 7 + dim)
+    x = (torch.randn(rows, dim, generator=g) * (0.5 + torch.rand(rows, 1, generator=g)) + 0.3).to(dtype)
+    w = (1 + 0.2 * torch.randn(dim, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(dim, generator=g)).to(dtype)
+    gy = torch.randn(rows, dim, generator=g).to(dtype)
+    f = lambda t: t.double().numpy()
+    y, mean, rstd = _launch.swish_layer_norm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    dx, dw, db = _launch.swish_layer_norm_bwd(gy.to(DEV), x.to(DEV), w.to(DEV), b.to(DEV), mean, rstd)
+    dx2, dw2, db2 = _launch.swish_layer_norm_bwd(gy.to(DEV), x.to(DEV), w.to(DEV), b.to(DEV), mean, rstd)
+    torch.cuda.synchronize()
+    ry = O.swish_layer_norm_fwd(f(x), f(w), f(b), 1e-5)
+    rdx, rdw, rdb = O.swish_layer_norm_bwd(f(gy), f(x), f(w), f(b), 1e-5)
+    name = str(dtype).replace("torch.", "")
+    m = record_parity("swish_layer_norm.y", y.double().cpu().numpy(), ry, name)
+    assert m["rel_fro"] <= GATE[dtype], m
+    m = record_parity("swish_layer_norm.dx", dx.double().cpu().numpy(), rdx, name)
+    assert m["rel_fro"] <= GATE[dtype], m
+    assert dw.dtype == torch.float32 and db.dtype == torch.float32
+    assert _rel(dw, rdw) <= 1e-4 and _rel(db, rdb) <= 1e-4
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)       # fixed reduction order
+    xs = f(x)
+    np.testing.assert_allclose(mean.cpu().numpy(), xs.mean(axis=1), rtol=2e-5, atol=2e-6)
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+
+
+def test_swish_layer_norm_shapes_dtypes_and_empty_input():
+    """3-D input (the preprocessors call it on (B, N, D)), fp32 parameters with bf16 activations (the modules keep fp32
+    parameters), no rows"""
+    from generative_recommenders_amd.ops.layer_norm import LayerNorm, SwishLayerNorm, swish_layer_norm
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 17, 512, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    m = SwishLayerNorm(512).to(DEV)
+    y = m(x)
+    assert y.shape == x.shape and y.dtype == torch.bfloat16
+    y.float().sum().backward()
+    assert m.weight.grad.dtype == torch.float32 and m.weight.grad.shape == (512,) and x.grad.shape == x.shape
+    ref = O.swish_layer_norm_fwd(x.detach().double().cpu().numpy().reshape(-1, 512), np.ones(512), np.zeros(512), 1e-5)
+    assert _rel(y.reshape(-1, 512), ref) <= GATE[torch.bfloat16]
+    e = torch.zeros(0, 512, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    ye = swish_layer_norm(e, m.weight, m.bias, 1e-5)
+    assert ye.shape == (0, 512)
+    ln = LayerNorm(512).to(DEV)
+    z = ln(x.detach())
+    assert z.shape == x.shape and abs(float(z.float().mean())) < 1e-2
+    with pytest.raises(RuntimeError):
+        swish_layer_norm(torch.randn(4, 512), m.weight.cpu(), m.bias.cpu())           # CPU tensors: no fallback

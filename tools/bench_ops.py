@@ -51,6 +51,8 @@ rows = {
     "complete_cumsum (B=1024, int64)": (lambda: _launch.complete_cumsum(lengths), 2 * B * 8),
     "layer_norm_fwd": (lambda: _launch.layer_norm_fwd(x, w, b, 1e-6), 2 * L * D * es),
     "layer_norm_bwd": (lambda: _launch.layer_norm_bwd(dy, x, w, mean, rstd), 3 * L * D * es),
+    "swish_layer_norm_fwd": (lambda: _launch.swish_layer_norm_fwd(x, w, b, 1e-5), 2 * L * D * es),
+    "swish_layer_norm_bwd": (lambda: _launch.swish_layer_norm_bwd(dy, x, w, b, mean, rstd), 3 * L * D * es),
     "norm_mul_fwd (group norm, concat [u, attn, y])": (lambda: _launch.norm_mul_fwd(x, u, gw, gb, 1e-6, H, D // H, True, True), 5 * L * D * es),
     "norm_mul_bwd (group norm, concat)": (lambda: _launch.norm_mul_bwd(dy3, x, u, gw, gb, m2, r2, H, D // H, True, True), 7 * L * D * es),
     "silu_fwd on the u slice of uvqk": (lambda: _launch.silu_fwd(uvqk[:, :D]), 2 * L * D * es),
