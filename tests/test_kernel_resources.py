@@ -72,8 +72,10 @@ def test_no_kernel_spills_or_uses_scratch():
     # reference's kernels take any D); every BASELINE configuration (<= 1024) runs the narrow instances, which may not spill.
     accepted = accepted + ("N4hstu3nw4",)
     # u * GroupNorm(attn) backward with SiLU applied on the fly (single-chunk rows): 98 registers, asked to fit the 96 of a
-    # fifth wave per SIMD -- 2 spilled registers, measured 4 % faster than 4 waves without (profiles/r03_ab_row_passes_silu.txt)
-    bounded.update({"norm_mul_bwd_gn_kernelIDF16bLi8ELi1ELb1E": 2, "norm_mul_bwd_gn_kernelIDF16_Li8ELi1ELb1E": 2})
+    # fifth wave per SIMD -- 2 spilled registers, measured 4 % faster than 4 waves without (profiles/r03_ab_row_passes_silu.txt);
+    # 6 since the sigmoid goes through the hardware exp2 / rcp (round 5): layer step 13.36-13.42 ms against 13.41-13.47 for
+    # 4 waves without a spill, three alternating runs (profiles/r05_norm_w5_ab.txt)
+    bounded.update({"norm_mul_bwd_gn_kernelIDF16bLi8ELi1ELb1E": 6, "norm_mul_bwd_gn_kernelIDF16_Li8ELi1ELb1E": 6})
     # The short-sequence research backward (one workgroup per CU, one wave per SIMD: 344 registers incl. AGPRs) parks one
     # 8-byte value in scratch at entry (no register spilled in the loops' bodies)
     bounded.update({"hstu_attn_bwd_solo_bias_kernel": 0})
