@@ -100,6 +100,6 @@ def test_swish_layer_norm_shapes_dtypes_and_empty_input():
     assert ye.shape == (0, 512)
     ln = LayerNorm(512).to(DEV)
     z = ln(x.detach())
-    assert z.shape == x.shape and abs(float(z.float().mean())) < 1e-2
+    assert z.shape == x.shape and abs(float(z.detach().float().mean())) < 1e-2
     with pytest.raises(RuntimeError):
         swish_layer_norm(torch.randn(4, 512), m.weight.cpu(), m.bias.cpu())           # CPU tensors: no fallback
