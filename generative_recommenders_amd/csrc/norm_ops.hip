@@ -17,6 +17,9 @@
                        // SiLU fwd 81 -> 62 us, the others -1..-3 %, layer step unchanged); loads mixed (norm_mul bwd +6 %): off.  profiles/r04_norm_nt.txt
 #endif
 
+#ifndef NORM_DROP_ROUNDS
+#define NORM_DROP_ROUNDS 1     // multiply-xorshift rounds of the fused dropout's generator (norm_kernels.inc, drop_hash)
+#endif
 #ifndef NORM_FAST_SIGMOID
 #define NORM_FAST_SIGMOID 1
 #endif

@@ -1,6 +1,8 @@
 """Pins the numpy oracle (oracle/hstu_oracle.py) to the golden vectors minted from
 the reference's own PyTorch path (tests/golden/make_golden.py).  CPU only."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -327,3 +329,21 @@ def test_oracle_matches_reference_sampled_softmax_padded_entry():
     B, N, D = c["out_emb"].shape
     np.testing.assert_allclose(O.jagged_to_padded_dense(dq, off, N), c["dout_emb"], rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(O.jagged_to_padded_dense(dpos, off, N), c["dsup_emb"], rtol=2e-4, atol=2e-6)
+
+
+def test_dropout_generator_statistics():
+    """the counter-based generator of the fused dropout, as the oracle restates it (one murmur3 finaliser per element pair): keep
+    rate per tensor / row / column, neighbour / row / seed correlations -- z-scores of independent draws (tools/dropout_hash_stats.py
+    prints the table)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("dropout_hash_stats", os.path.join(os.path.dirname(__file__), "..", "tools", "dropout_hash_stats.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed, p in ((42, 0.1), (2 ** 40 + 7, 0.5)):
+        z = mod.z_scores(seed, 1024, 1536, p)
+        assert z["mean"] < 4.5 and z["column max"] < 5.5 and z["row max"] < 5.5, z
+        assert all(v < 4.5 for k, v in z.items() if k not in ("mean", "column max", "row max")), z
+    # an element index beyond 2^33: the pair index's high word enters the key (no repetition of the first 2^33 elements' mask)
+    a = O.dropout_keep_mask(7, 1, 4096, 0.5)[0]
+    assert a.shape == (1, 4096) and 0.4 < a.mean() < 0.6
