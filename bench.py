@@ -62,6 +62,8 @@ WORKLOADS = {
                                    "bias inside the short-sequence kernels, lengths as C3"),
     "C4": (200, 4, 64, 1024, "one rank's shard (1024 users) of the DP-8 synthetic ML-3B batch, M-jag lengths"),
     "C5": (8192, 16, 64, 32, "HSTU-large M-FALCON microbatch: 256 candidates per user against L = randint(7372, 8192) cached rows, forward only, 24 layers back to back"),
+    "L2048": (2048, 4, 128, 512, "long-sequence training point of the reference's own sweep (ops/benchmarks/hstu_attention_bench.py:139, seq_len 2^8..2^12): "
+                                  "L = randint(1843, 2048), num_targets = randint(1, 21); the general multi-key-block backward"),
 }
 
 
@@ -91,7 +93,7 @@ def attention_section(args, rank, world, device, telem=None):
     N, H, d = args.max_seq_len, args.heads, args.head_dim
     B = args.users_per_gpu
     gen = torch.Generator(device=device).manual_seed(1001 + rank)
-    lengths = make_lengths(wl if wl not in ("M-targets", "C4", "C5") else "M-jag", B, N, gen, device)
+    lengths = make_lengths(wl if wl not in ("M-targets", "C4", "C5", "L2048") else "M-jag", B, N, gen, device)
     off = dp.local_offsets(lengths)
     L = int(off[-1].item())
     dtype = torch.bfloat16
@@ -151,7 +153,7 @@ def attention_section(args, rank, world, device, telem=None):
             q, k, v = (t.permute(1, 0, 2).contiguous().permute(1, 0, 2) for t in (q, k, v))
         dout = torch.randn(L, H, d, device=device, dtype=dtype, generator=gen)
         nt = None
-        if wl == "M-targets":
+        if wl in ("M-targets", "L2048"):
             nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
         dfused = torch.empty_like(fused)
         dq, dk, dv = torch.split(dfused, [d, d, d], dim=-1)
@@ -276,8 +278,12 @@ def rooflines(att, workload):
 # the other shapes north_star names, run for a few steps after the headline so that the driver's record carries them
 # (M-full-1024: the metric shape at the PER-GPU batch of the 8-GPU metric -- 8192 users over 8 ranks: launch ramp, first prologue
 # and last tail weigh 8x more than at 8192 users per GPU)
-EXTRA_WORKLOADS = [("M-jag", {}), ("M-full-1024", {"workload": "M-full", "users": 1024, "steps": 96, "warmup": 20}), ("M-full-d64", {"workload": "M-full", "head_dim": 64}),
-                   ("C2", {}), ("C3", {}), ("C3-bias", {})]
+# (M-targets: what DLRM-v3 runs -- modules/dlrm_hstu.py:207-214 target_aware=True, sort_by_length=True; C4 / C5 / L2048: sub-10-ms or
+# long steps, their own step counts)
+EXTRA_WORKLOADS = [("M-jag", {}), ("M-targets", {"sort_by_length": True}),
+                   ("M-full-1024", {"workload": "M-full", "users": 1024, "steps": 96, "warmup": 20}), ("M-full-d64", {"workload": "M-full", "head_dim": 64}),
+                   ("C2", {}), ("C3", {}), ("C3-bias", {}), ("C4", {"steps": 48, "warmup": 10}), ("C5", {"steps": 3, "warmup": 1}),
+                   ("L2048", {"steps": 6, "warmup": 2})]
 
 
 def extra_workloads(args, rank, world, device):
@@ -288,7 +294,7 @@ def extra_workloads(args, rank, world, device):
         n, h, d, users, _ = WORKLOADS[a.workload]
         a.max_seq_len, a.heads, a.head_dim, a.users_per_gpu = n, h, over.get("head_dim", d), over.get("users", users)
         a.steps, a.warmup = over.get("steps", args.extra_steps), over.get("warmup", over.get("steps", 24) // 8)   # (sub-millisecond steps: more of them, or the loop is over before the clocks have settled)
-        a.sort_by_length = a.workload == "C3"
+        a.sort_by_length = over.get("sort_by_length", a.workload == "C3")
         a.parity_users = 0          # (the headline batch carries the oracle check)
         try:
             att = attention_section(a, rank, world, device)
@@ -296,6 +302,7 @@ def extra_workloads(args, rank, world, device):
             out[name] = {"user_seqs_per_s": world * att["users"] * a.steps / att["elapsed"], "steps": a.steps,
                          "users_per_gpu": a.users_per_gpu, "max_seq_len": n, "heads": h, "head_dim": a.head_dim,
                          "fwd_ms": round(att["fwd_ms"], 4), "bwd_ms": round(att["bwd_ms"], 4), "step_spread": att["step_spread"], "bound": main["bound"],
+                         "prewarm_steps": att["prewarm_steps"], "warmup": a.warmup, "sort_by_length": bool(a.sort_by_length),
                          "frac_fwd": round(fwd["frac"], 4), "frac_bwd": round(main["frac"], 4), "frac_fwd_bwd": round(both["frac"], 4),
                          "kernels": att["kernels"], "what": WORKLOADS[a.workload][4]}
             # HBM bytes of the committed PMC passes of the same workload / kernels (None: no pass on this instantiation)
@@ -307,6 +314,8 @@ def extra_workloads(args, rank, world, device):
                     tr[side] = {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
                                 "over_algorithmic": round(e["hbm_bytes_per_launch"] / att[side + "_bytes"], 4)}
             out[name]["traffic"] = dict(tr, file="profiles/" + fname) if tr else None
+            if ent is not None and ent.get("stale"):
+                out[name]["traffic_stale"] = ent["stale"]["why"]
         except Exception as e:  # the headline number must survive a failure here
             out[name] = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
@@ -505,8 +514,9 @@ def parity_sample(q, k, v, dout, out, dq, dk, dv, off, nt, N, alpha, n_users=32,
 
 
 def rccl_section(world, device, nbytes=22 << 20):
-    """communicator size + bus bandwidth of the all-reduce the layer step performs (22 MB of fp32 gradients)"""
-    if world == 1 or not dist.is_initialized():
+    """communicator size + bus bandwidth of the all-reduce the layer step performs (22 MB of fp32 gradients); with ONE rank
+    (a one-rank RCCL communicator on a one-GPU box) the time of the library's launch path, bus bandwidth 0 by definition"""
+    if not dist.is_initialized():
         return None
     t = torch.ones(nbytes // 4, dtype=torch.float32, device=device)
     for _ in range(3):
@@ -545,7 +555,7 @@ def layer_section(args, rank, world, device, telem=None):
     gy = torch.randn(L, D, device=device, dtype=torch.bfloat16, generator=gen)
     nt = torch.minimum(torch.randint(1, 21, (B,), generator=gen, device=device), lengths)
 
-    def timed(recompute, dropout, fuse=True, telem=None, replay=0):
+    def timed(recompute, dropout, fuse=True, telem=None, replay=0, force_collectives=False):
         """recompute=True: the reference's STULayerConfig defaults (normed x, uvqk and y recomputed in the backward --
         a memory saving sized for 80 GB parts); False: everything kept (3 layers x 1024 users: 2.4 GB of 288).
         dropout: output_dropout_ratio of the layers (DLRM-v3 trains with hstu_linear_dropout_rate = 0.1,
@@ -558,7 +568,8 @@ def layer_section(args, rank, world, device, telem=None):
         for layer in stack._stu_layers:
             layer.fuse_layer = fuse        # True: the layer as one autograd node (default); False: the reference's two nodes
         # one bucket per layer, its all-reduce launched from inside backward when the layer's last gradient is in
-        reducer = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in stack._stu_layers], overlap=True)
+        reducer = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in stack._stu_layers], overlap=True,
+                                        single_rank_collectives=force_collectives)
 
         def step():
             for p in stack.parameters():
@@ -612,6 +623,17 @@ def layer_section(args, rank, world, device, telem=None):
     elapsed_two, _ = timed(True, p_drop, fuse=False)
     elapsed, stack = timed(True, p_drop, telem=telem, replay=min(args.layer_steps, 5))
     nparams = sum(p.numel() for p in stack.parameters())
+    one_rank = None
+    if world == 1 and dist.is_initialized():
+        # the same step with the buckets REALLY all-reduced on the one-rank RCCL communicator (hooks -> staging copy -> asynchronous
+        # ncclAllReduce on the communicator's stream -> p.grad): the collective path's cost on this box, not part of ms_per_step
+        try:
+            e1, _ = timed(True, p_drop, force_collectives=True)
+            one_rank = dict(ms_per_step=e1 / args.layer_steps * 1e3, backend=dist.get_backend(),
+                            what="layer step with every bucket all-reduced on a ONE-rank communicator (identity sums; tests/test_rccl_gpu.py "
+                                 "checks them bit for bit)")
+        except Exception as e:  # pragma: no cover
+            one_rank = {"error": repr(e)[:300]}
     gemm_flops = 3 * 3 * L * (2 * D * 4 * D + 2 * 3 * D * D)  # 3 layers x (fwd + 2x bwd) x (uvqk + output)
     return dict(users_per_gpu=B, steps=args.layer_steps, ms_per_step=elapsed / args.layer_steps * 1e3,
                 user_seqs_per_s=world * B * args.layer_steps / elapsed, params=nparams,
@@ -624,7 +646,7 @@ def layer_section(args, rank, world, device, telem=None):
                                      user_seqs_per_s=world * B * args.layer_steps / elapsed_two),
                 dropout_off=dict(ms_per_step=elapsed_nodrop / args.layer_steps * 1e3,
                                  user_seqs_per_s=world * B * args.layer_steps / elapsed_nodrop),
-                allreduce_bytes=nparams * 4,
+                allreduce_bytes=nparams * 4, one_rank_collectives=one_rank,
                 no_recompute=dict(ms_per_step=elapsed_keep / args.layer_steps * 1e3,
                                   user_seqs_per_s=world * B * args.layer_steps / elapsed_keep),
                 gemm_mfma_frac_if_all_time_were_gemm=gemm_flops * args.layer_steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,
@@ -706,6 +728,23 @@ def cpu_baseline(args):
     the host cores, fp32, on a bounded sample of the same workload."""
     from oracle.dense_torch import dense_hstu_mha
 
+    # SURVEY 8(d) names the reference's own hstu_mha(kernel=HammerKernel.PYTORCH).  It is Python under /root/reference, which exists
+    # in the build container only (and may not travel to the GPU box): where it is importable it IS what gets timed (kind
+    # "reference"); everywhere else the port below, with the measured port / reference ratio of the same sample next to it
+    # (profiles/r06_cpu_reference_vs_port.json, tools/cpu_reference_vs_port.py: identical results, 0.93-1.25x the speed).
+    ref_mha = None
+    if os.path.isdir("/root/reference/generative_recommenders") and os.environ.get("HSTU_BENCH_CPU_REFERENCE", "1") != "0":
+        try:
+            sys.path.insert(0, "/root/reference")
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            import _fbgemm_shim  # noqa: F401
+            from generative_recommenders.common import HammerKernel
+            from generative_recommenders.ops.hstu_attention import hstu_mha as _ref
+
+            ref_mha = lambda n, a, q_, k_, v_, o_: _ref(max_seq_len=n, alpha=a, q=q_, k=k_, v=v_, seq_offsets=o_, causal=True,
+                                                       dropout_pr=0.0, training=True, kernel=HammerKernel.PYTORCH)
+        except Exception:
+            ref_mha = None
     # more threads than this only add synchronisation cost on a (256, 4, 200, 200) problem
     cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
     torch.set_num_threads(cores)
@@ -725,15 +764,24 @@ def cpu_baseline(args):
     # (bounded: the default bench run must stay within minutes whatever the host is)
     while len(times) < 2 or (sum(times[1:]) < 10.0 and len(times) < 41):
         t0 = time.perf_counter()
-        out = dense_hstu_mha(N, d**-0.5, q, k, v, off)
+        out = ref_mha(N, d**-0.5, q, k, v, off) if ref_mha is not None else dense_hstu_mha(N, d**-0.5, q, k, v, off)
         out.backward(do)
         times.append(time.perf_counter() - t0)
         q.grad = k.grad = v.grad = None
     med = statistics.median(times[1:])
-    res = dict(value=B / med, unit="user-seqs/s", cores=cores, kind="port",
+    res = dict(value=B / med, unit="user-seqs/s", cores=cores, kind="reference" if ref_mha is not None else "port",
                sample=f"{B} users of the same length distribution, fp32, fwd+bwd, median of {len(times) - 1} passes "
                       f"after 1 warm-up ({med * 1e3:.0f} ms each, {sum(times[1:]):.1f} s of CPU work); "
-                      f"oracle/dense_torch.py = reference pt_hstu_attention.py algorithm")
+                      + ("the reference's hstu_mha(kernel=HammerKernel.PYTORCH), imported from /root/reference" if ref_mha is not None else
+                         "oracle/dense_torch.py = reference pt_hstu_attention.py algorithm (the reference itself is not on this box)"))
+    try:
+        rv = json.load(open(os.path.join(ROOT, "profiles", "r06_cpu_reference_vs_port.json")))
+        w = rv["workloads"].get(args.workload) or rv["workloads"]["M-jag"]
+        res["port_over_reference"] = {"ratio": round(w["port_over_reference"], 3), "threads": rv["threads"], "where": rv["host"],
+                                      "max_rel_diff_of_results": w["max_rel_diff_of_results"],
+                                      "file": "profiles/r06_cpu_reference_vs_port.json"}
+    except Exception:
+        pass
     try:
         res["layer"] = cpu_baseline_layer(args, cores)
     except Exception as e:  # pragma: no cover
@@ -782,11 +830,33 @@ def cpu_baseline_layer(args, cores):
                        f"({med * 1e3:.0f} ms each); oracle/dense_torch.py::dense_stu_stack = reference modules/stu.py PyTorch path")
 
 
-TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json")
+
+# The HBM-traffic figures are counters of committed rocprofv3 passes, not of this run: they describe THE KERNELS THAT WERE PROFILED.
+# Every entry therefore carries the SHA-256 of the attention kernels' sources it was taken on (``sources_sha256``, written by
+# tools/make_pmc_traffic.py); an entry without one, or with another one, is STALE -- the kernels were edited after the passes --
+# and is refused: ``traffic`` stays null and ``traffic_stale`` says why.
+KERNEL_SOURCE_GLOBS = ("hstu_attn_*.cuh", "hstu_common.cuh", "attn_*.cuh", "attn_*.hip", "capi_internal.h")
+
+
+def kernel_sources_sha256():
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "generative_recommenders_amd", "csrc")
+    files = sorted({f for g in KERNEL_SOURCE_GLOBS for f in glob.glob(os.path.join(base, g))})
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def traffic_entry(workload, users, head_dim, heads):
-    """the committed PMC passes of this (workload, users, head dim, heads) at bf16, or None"""
+    """(file, entry) of the committed PMC passes of this (workload, users, head dim, heads) at bf16 taken on the CURRENT kernel
+    sources; a matching entry of other sources comes back as (file, {"stale": reason}); (None, None) when there is none"""
+    cur = None
+    stale = (None, None)
     for name in TRAFFIC_FILES:
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -796,38 +866,39 @@ def traffic_entry(workload, users, head_dim, heads):
             src = ent.get("source", {"workload": "M-full", "users_per_gpu": 8192, "head_dim": 128, "heads": 4, "dtype": "bf16"})
             if (src.get("workload") == workload and src.get("users_per_gpu") == users and src.get("head_dim") == head_dim
                     and src.get("heads") == heads and src.get("dtype") == "bf16"):
-                return name, ent
-    return None, None
+                cur = cur or kernel_sources_sha256()
+                sha = ent.get("sources_sha256", tr.get("sources_sha256"))
+                if sha == cur:
+                    return name, ent
+                if stale[0] is None:
+                    stale = (name, {"stale": {"file": "profiles/" + name, "why": "the attention kernel sources changed after these PMC passes were taken"
+                                              if sha else "entry carries no hash of the kernel sources it was taken on",
+                                              "entry_sources_sha256": sha, "current_sources_sha256": cur}})
+    return stale
 
 
 def attach_traffic(res, args, att):
-    """HBM bytes from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected with tools/prof_pmc.sh;
-    counters cannot be read from inside the process) -- attached only when the run's workload, users, head dim and
-    dtype are the ones the passes were taken on"""
+    """HBM bytes from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected with tools/prof_traffic.sh, written
+    by tools/make_pmc_traffic.py; counters cannot be read from inside the process) -- attached only when the run's workload,
+    users, head dim and dtype are the ones the passes were taken on AND the kernel sources are the ones that were profiled"""
     res["roofline"]["traffic"] = None
-    for name in TRAFFIC_FILES:
-        path = os.path.join(ROOT, "profiles", name)
-        try:
-            tr = json.load(open(path))
-        except Exception:
-            continue
-        for ent in tr.get("entries", [tr]):
-            src = ent.get("source", {"workload": "M-full", "users_per_gpu": 8192, "head_dim": 128, "heads": 4, "dtype": "bf16"})
-            same = (src.get("workload") == args.workload and src.get("users_per_gpu") == args.users_per_gpu
-                    and src.get("head_dim") == args.head_dim and src.get("heads") == args.heads and src.get("dtype") == "bf16")
-            if not same:
-                continue
-            dom = ent.get("bwd", ent["fwd"])            # forward-only workloads: the forward is the dominant kernel
-            if dom.get("kernel") not in (res["roofline"].get("kernel"), None):
-                continue                                # the passes were taken on another instantiation: not this run's traffic
-            per = dom["hbm_bytes_per_launch"]
-            res["roofline"]["traffic"] = per
-            res["roofline"]["traffic_over_algorithmic"] = per / res["roofline"]["algorithmic_bytes_per_launch"]
-            res["roofline"]["traffic_source"] = dict(file="profiles/" + name, kernel=dom.get("kernel"), **src)
-            if "roofline_fwd" in res and "bwd" in ent:
-                res["roofline_fwd"]["traffic"] = ent["fwd"]["hbm_bytes_per_launch"]
-                res["roofline_fwd"]["traffic_source"] = dict(file="profiles/" + name, kernel=ent["fwd"].get("kernel"), **src)
-            return
+    name, ent = traffic_entry(args.workload, args.users_per_gpu, args.head_dim, args.heads)
+    if ent is None:
+        return
+    if ent.get("stale"):
+        res["roofline"]["traffic_stale"] = ent["stale"]
+        return
+    src = ent.get("source", {})
+    dom = ent.get("bwd", ent["fwd"])            # forward-only workloads: the forward is the dominant kernel
+    if dom.get("kernel") not in (res["roofline"].get("kernel"), None):
+        return                                  # the passes were taken on another instantiation: not this run's traffic
+    per = dom["hbm_bytes_per_launch"]
+    res["roofline"]["traffic"] = per
+    res["roofline"]["traffic_over_algorithmic"] = per / res["roofline"]["algorithmic_bytes_per_launch"]
+    res["roofline"]["traffic_source"] = dict(file="profiles/" + name, kernel=dom.get("kernel"), sources_sha256=ent.get("sources_sha256"), **src)
+    if "roofline_fwd" in res and "bwd" in ent:
+        res["roofline_fwd"]["traffic"] = ent["fwd"]["hbm_bytes_per_launch"]
+        res["roofline_fwd"]["traffic_source"] = dict(file="profiles/" + name, kernel=ent["fwd"].get("kernel"), **src)
 
 
 def selftest_dist(args, rank, world):
@@ -886,7 +957,18 @@ def run(args):
         except Exception as e:  # pragma: no cover
             cpu_res = {"error": repr(e)[:300]}
         torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
-    rank, local_rank, world = dp.init_from_env()
+    # (--gpus 1: a ONE-rank RCCL communicator -- the library, its version string and the reducer's stream discipline on the one GPU
+    # there is: the layer section's gradient buckets then really go through ncclAllReduce; HSTU_BENCH_SINGLE_RANK_RCCL=0 turns it off)
+    single = int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("HSTU_BENCH_SINGLE_RANK_RCCL", "1") != "0"
+    if single:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    try:
+        rank, local_rank, world = dp.init_from_env(single_rank_group=single)
+    except Exception as e:  # pragma: no cover -- the headline number must survive a communicator that does not come up
+        if not single:
+            raise
+        print(f"bench.py: one-rank process group not available ({e!r}); continuing without", file=sys.stderr)
+        rank, local_rank, world = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one device per rank (init_from_env refuses anything else under RCCL); the modulo only serves the gloo rehearsal of the
@@ -920,6 +1002,7 @@ def run(args):
             "users_per_gpu": args.users_per_gpu, "rows_per_gpu": att["rows"], "sort_by_length": args.sort_by_length, "parallelism": f"dp{world} (no collective: attention has no parameters)",
         },
         "device_ms_per_step": att["device_ms_per_step"], "step_spread": att["step_spread"],
+        "prewarm_steps": att["prewarm_steps"], "prewarm_s": getattr(args, "prewarm_s", 0.3),
     }
     res["roofline"], res["roofline_fwd"], res["roofline_fwd_bwd"] = rooflines(att, args.workload)
     res["parity_at_this_size"] = att["parity"] if att.get("parity") else (
@@ -942,7 +1025,7 @@ def run(args):
             c["attn_fwd_bwd_bytes_over_read_stream"] = round(res["roofline_fwd_bwd"]["achieved"] / c["read_stream_GBps"], 3)
         except Exception as e:  # pragma: no cover
             res["calibration"] = {"error": repr(e)[:300]}
-    if world > 1:
+    if dist.is_initialized():
         try:
             res["rccl"] = rccl_section(world, device)
             res["rccl"]["job"] = dp.describe_ranks(device)

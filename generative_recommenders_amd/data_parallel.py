@@ -18,14 +18,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False) -> Tuple[int, int, int]:
     """(rank, local_rank, world_size) from torchrun-style env; initialises the process group
-    when WORLD_SIZE > 1.  MASTER_ADDR defaults to 127.0.0.1 (container hostnames may not
+    when WORLD_SIZE > 1 -- or, with ``single_rank_group``, also for a lone rank (a one-rank RCCL
+    communicator: the only way to put the library and the reducer's stream discipline on the
+    hardware of a one-GPU box).  MASTER_ADDR defaults to 127.0.0.1 (container hostnames may not
     resolve)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         # Hosts whose driver only supports dmabuf IPC: without this RCCL's buffer exchange fails in hipIpcGetMemHandle.  The HSA
         # runtime reads it when the process first touches the GPU -- so it only helps when nothing has touched it yet.
         if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
@@ -126,14 +128,28 @@ class GradientAllReducer:
     launch latency once.  Larger models split at ``bucket_bytes``.
     """
 
+    # overlap mode: every bucket carries ONE extra element behind its gradients, set to a small integer that names the bucket
+    # before its all-reduce is issued.  Collectives pair up across ranks by issue order, so if the ranks ever disagree on that
+    # order (a bucket launched from a hook on one rank and late on another) buffers of DIFFERENT buckets are summed -- and with
+    # equally sized per-layer buckets nothing fails.  The tag makes that visible in the data the mispaired collective itself
+    # returns: every rank that took part in a wrong pairing reads a sum that is not world x its own tag.  No extra collective,
+    # nothing that could itself mispair; reading the tags is one small device-to-host copy, done on the first ``check_first``
+    # calls of reduce() and every ``check_every``-th after that.
+    TAG_MOD = 7      # tags 1..7: world x tag <= 56 stays exact in bf16 buckets up to 8 ranks (mean: <= 7 everywhere)
+
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True,
                  buckets: Optional[Sequence[Iterable[torch.nn.Parameter]]] = None, overlap: bool = False,
-                 check_every: int = 0):
+                 check_every: int = 50, check_first: int = 3, single_rank_collectives: bool = False):
         """``buckets``: explicit parameter groups (e.g. one per layer) instead of the byte-size split of ``params``.
         ``overlap``: launch a bucket's all-reduce from inside backward, as soon as its last gradient has been
-        accumulated (hooks); ``reduce()`` then only waits.  The reference's DDP does the same (train.py:269)."""
+        accumulated (hooks); ``reduce()`` then only waits.  The reference's DDP does the same (train.py:269).
+        ``single_rank_collectives``: issue the collectives also in a one-rank group (tests / bench on a one-GPU box:
+        the hooks, the staging copy, the asynchronous all-reduce on the communicator's stream and the hand-back into
+        ``p.grad`` then run exactly as they do with 8 ranks; default: a lone rank skips them)."""
         self.average = average
-        self.check_every = int(check_every)     # overlap mode: every N-th reduce() compares the late-bucket sets across ranks (0: never)
+        self.check_every = int(check_every)     # overlap mode: the bucket tags are read back on every N-th reduce() (0: only the first calls)
+        self.check_first = int(check_first)
+        self.single_rank_collectives = bool(single_rank_collectives)
         self.buckets: List[List[torch.nn.Parameter]] = []
         if buckets is not None:
             # a bucket is ONE flat buffer: parameters of different dtypes (or devices) of a group get buckets of their own,
@@ -190,9 +206,29 @@ class GradientAllReducer:
                                f"{bucket[0].dtype} parameters on {bucket[0].device}")
         flat = self._flat[bi]
         if flat is None:
-            flat = torch.empty(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=bucket[0].device)
+            n = sum(p.numel() for p in bucket)
+            flat = torch.empty(n + 1, dtype=bucket[0].dtype, device=bucket[0].device)      # + the bucket's tag
             self._flat[bi] = flat
         return flat
+
+    def _collectives_on(self) -> bool:
+        return dist.is_initialized() and (dist.get_world_size() > 1 or self.single_rank_collectives)
+
+    def _tag(self, bi: int) -> float:
+        return float(bi % self.TAG_MOD + 1)
+
+    def _check_tags(self, reduced: List[int], world: int) -> None:
+        """the tags of the buckets all-reduced in this call, read back in one copy: world x tag (tag after the mean)"""
+        if not reduced:
+            return
+        got = torch.stack([self._flat[bi][-1].float() for bi in reduced]).cpu().tolist()
+        bad = [(bi, g) for bi, g in zip(reduced, got) if g != (self._tag(bi) if self.average else self._tag(bi) * world)]
+        if bad:
+            raise RuntimeError(
+                "GradientAllReducer(overlap=True): bucket tag mismatch after the all-reduce for bucket(s) "
+                f"{[bi for bi, _ in bad]} (read {[g for _, g in bad]}): the ranks issued their bucket collectives in different "
+                "orders, so gradients of different buckets were summed.  The set of parameters that receive a gradient in a "
+                "step must be the same on every rank (or use overlap=False).")
 
     def no_sync(self):
         """context manager for gradient accumulation: backward passes inside it only accumulate locally (into the bucket
@@ -231,7 +267,8 @@ class GradientAllReducer:
                 self._staged[bi] = []
             if not self._sync:
                 self._pending[bi] = len(self.buckets[bi])        # accumulate only: count the next backward from the top
-            elif dist.is_initialized() and dist.get_world_size() > 1:
+            elif self._collectives_on():
+                flat[-1] = self._tag(bi)
                 self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def remove_hooks(self) -> None:
@@ -246,30 +283,26 @@ class GradientAllReducer:
             # backward order, identical on every rank as long as every parameter gets a gradient everywhere.  A bucket that is
             # incomplete on this rank (parameters unused in this step) is reduced here -- zeros for the missing gradients --
             # in bucket order AFTER the hook-launched ones; a rank on which the same bucket was complete launched it from a
-            # hook already, and the two would pair different buffers.  PRECONDITION (documented, not detectable in time): the
-            # set of parameters that receive a gradient in a step is the same on every rank -- the model's parameter usage
-            # may not depend on a rank's data (otherwise: overlap=False).  No per-step state exchange, no host sync: by the
-            # time a mismatch could be seen, the mispaired collectives have been issued.  ``check_every = N > 0`` is a
-            # debugging aid for runs under a collective timeout: every N-th call all ranks exchange their late-bucket bitmap
-            # (one MAX all-reduce of the bitmap and its complement) and ALL of them raise when the bitmaps differ.
+            # hook already, and the two would pair different buffers.  PRECONDITION: the set of parameters that receive a
+            # gradient in a step is the same on every rank -- the model's parameter usage may not depend on a rank's data
+            # (otherwise: overlap=False).  A violation cannot be prevented here (by the time it could be seen the mispaired
+            # collectives have been issued) but it is DETECTED: see the bucket tags above.
             late = [bi for bi, w in enumerate(self._work) if w is None and self._pending[bi] != 0]
+            coll = self._collectives_on()
+            reduced = []
             for bi, work in enumerate(self._work):
                 if work is not None:
                     work.wait()
                     if self.average:
                         self._flat[bi].div_(world)
+                    reduced.append(bi)
             self._calls = getattr(self, "_calls", 0) + 1
-            if world > 1 and self._sync and self.check_every > 0 and self._calls % self.check_every == 0:
-                ref = self.buckets[0][0]
-                nb = len(self.buckets)
-                bits = [1 if bi in late else 0 for bi in range(nb)]
-                state = torch.tensor(bits + [1 - b for b in bits], dtype=torch.int32, device=ref.device)
-                dist.all_reduce(state, op=dist.ReduceOp.MAX)
-                # a bucket late on some ranks and not on others shows up as 1 in BOTH halves -- on every rank
-                if bool((state[:nb] + state[nb:] > 1).any()):
-                    raise RuntimeError("GradientAllReducer(overlap=True): the buckets with parameters that received no gradient differ "
-                                       "between ranks -- their collectives would pair different buffers.  Parameter usage must not "
-                                       "depend on a rank's data (or use overlap=False).")
+            if late and coll and self._sync and not getattr(self, "_warned_late", False):
+                import warnings
+
+                self._warned_late = True
+                warnings.warn(f"GradientAllReducer(overlap=True): bucket(s) {late} had parameters without a gradient in this step; "
+                              "they are reduced after the hook-launched ones, which is only correct when every rank sees the same set")
             for bi in late:
                 staged = self._staged[bi]
                 if staged:
@@ -278,7 +311,7 @@ class GradientAllReducer:
                     for q, v in staged:
                         q.grad = v
                     self._staged[bi] = []
-                if world == 1 or not self._sync:
+                if not coll or not self._sync:
                     continue
                 flat = self._bucket_flat(bi, self.buckets[bi][0])
                 for p in self.buckets[bi]:
@@ -286,12 +319,16 @@ class GradientAllReducer:
                         b2, o = self._slot[id(p)]
                         flat[o : o + p.numel()].zero_()
                         p.grad = flat[o : o + p.numel()].view_as(p)
+                flat[-1] = self._tag(bi)
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                 if self.average:
                     flat.div_(world)
+                reduced.append(bi)
+            if coll and self._sync and (self._calls <= self.check_first or (self.check_every > 0 and self._calls % self.check_every == 0)):
+                self._check_tags(reduced, world)
             self._reset()
             return
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not self._collectives_on():
             return
         world = dist.get_world_size()
         handles = []

@@ -56,20 +56,61 @@ def test_parity_sample_arithmetic_on_the_oracles_own_results():
     assert not bad["ok"] and bad["rel_fro"]["dk"] > 3.8e-3 and bad["users_checked"] == B
 
 
-def test_committed_traffic_file_matches_the_algorithmic_bytes_of_the_metric_shape():
+def test_traffic_entries_are_keyed_on_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py attaches committed PMC traffic only when the entry was taken on the kernel sources it runs on: an entry
+    stamped with the current hash is used, one with another stamp (or none) comes back as stale and is refused"""
     bench = _bench()
+    cur = bench.kernel_sources_sha256()
+    assert len(cur) == 64 and cur == bench.kernel_sources_sha256()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    src = {"workload": "M-full", "users_per_gpu": 8192, "head_dim": 128, "heads": 4, "dtype": "bf16"}
+    side = lambda k, b: {"kernel": k, "hbm_bytes_per_launch": b}
+    fresh = {"source": src, "sources_sha256": cur, "fwd": side("f", 6.7e9), "bwd": side("b", 11.7e9)}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_sources_sha256", lambda: cur)
+    json.dump({"entries": [dict(fresh, sources_sha256="0" * 64)]}, open(prof / bench.TRAFFIC_FILES[0], "w"))
     name, ent = bench.traffic_entry("M-full", 8192, 128, 4)
-    assert name == bench.TRAFFIC_FILES[0] and ent is not None
-    rows = 8192 * 200
-    for side, per_token in (("fwd", 4 * 4 * 128 * 2), ("bwd", 7 * 4 * 128 * 2)):
-        ratio = ent[side]["hbm_bytes_per_launch"] / (rows * per_token)
-        assert 0.95 < ratio < 1.05, (side, ratio)
+    assert name == bench.TRAFFIC_FILES[0] and "stale" in ent and "changed" in ent["stale"]["why"]
+    res = {"roofline": {"kernel": "b", "algorithmic_bytes_per_launch": 11.744e9}, "roofline_fwd": {}}
+    args = type("A", (), dict(workload="M-full", users_per_gpu=8192, head_dim=128, heads=4))
+    bench.attach_traffic(res, args, None)
+    assert res["roofline"]["traffic"] is None and "traffic_stale" in res["roofline"]
+    json.dump({"entries": [{k: v for k, v in fresh.items() if k != "sources_sha256"}]}, open(prof / bench.TRAFFIC_FILES[0], "w"))
+    assert "no hash" in bench.traffic_entry("M-full", 8192, 128, 4)[1]["stale"]["why"]
+    json.dump({"entries": [fresh]}, open(prof / bench.TRAFFIC_FILES[0], "w"))
+    name, ent = bench.traffic_entry("M-full", 8192, 128, 4)
+    assert ent is fresh or ent == fresh
+    res = {"roofline": {"kernel": "b", "algorithmic_bytes_per_launch": 11.744e9}, "roofline_fwd": {}}
+    bench.attach_traffic(res, args, None)
+    assert res["roofline"]["traffic"] == 11.7e9 and res["roofline_fwd"]["traffic"] == 6.7e9
+    assert bench.traffic_entry("C3", 8192, 16, 4) == (None, None)
+
+
+def test_committed_traffic_entries_match_the_algorithmic_bytes_of_the_metric_shape():
+    """whatever committed entry of the metric shape there is -- fresh or stale -- was measured at ~1.00x the algorithmic bytes"""
+    bench = _bench()
+    found = 0
+    for name in bench.TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        for ent in json.load(open(path)).get("entries", []):
+            src = ent.get("source", {})
+            if (src.get("workload"), src.get("users_per_gpu"), src.get("head_dim"), src.get("heads")) != ("M-full", 8192, 128, 4):
+                continue
+            found += 1
+            rows = 8192 * 200
+            for side, per_token in (("fwd", 4 * 4 * 128 * 2), ("bwd", 7 * 4 * 128 * 2)):
+                ratio = ent[side]["hbm_bytes_per_launch"] / (rows * per_token)
+                assert 0.95 < ratio < 1.05, (name, side, ratio)
+    assert found >= 1
 
 
 def test_workload_table_and_lengths():
     bench = _bench()
     gen = torch.Generator().manual_seed(0)
     for wl, (n, h, d, users, _) in bench.WORKLOADS.items():
-        ln = bench.make_lengths(wl if wl not in ("M-targets", "C4", "C5") else "M-jag", 64, n, gen, "cpu")
+        ln = bench.make_lengths(wl if wl not in ("M-targets", "C4", "C5", "L2048") else "M-jag", 64, n, gen, "cpu")
         assert ln.shape == (64,) and int(ln.max()) <= n and int(ln.min()) >= 0
     assert float(np.mean(bench.make_lengths("M-full", 8, 200, gen, "cpu").numpy())) == 200.0

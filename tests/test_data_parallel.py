@@ -162,6 +162,86 @@ def test_gloo_world2_overlapped_per_layer_buckets(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def _worker_mispaired(rank, world, port, out_dir):
+    """parameter usage that depends on the rank -- the documented precondition violated: rank 0's second layer gets no
+    gradient, so its bucket is late there while rank 1 launches it from a hook; the collectives pair bucket 0 with bucket 1
+    (equal sizes: nothing fails inside gloo / RCCL).  The bucket tags make BOTH ranks raise in reduce()."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import warnings
+
+    from generative_recommenders_amd import data_parallel as dp
+
+    dp.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    l0, l1 = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    red = dp.GradientAllReducer(None, buckets=[l0.parameters(), l1.parameters()], overlap=True, average=False)
+    x = torch.randn(3, 4)
+    y = l0(x) if rank == 0 else l1(l0(x))
+    y.sum().backward()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            red.reduce()
+            raise AssertionError("expected a bucket tag mismatch")
+        except RuntimeError as e:
+            assert "tag mismatch" in str(e), str(e)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_mispaired_buckets_are_detected(tmp_path):
+    port = 29750 + (os.getpid() % 100)
+    mp.spawn(_worker_mispaired, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _worker_single(rank, world, port, out_dir):
+    """a ONE-rank group with single_rank_collectives=True: hooks -> staging copy -> asynchronous all-reduce -> p.grad, and
+    no_sync() in between, give bit for bit the gradients of a run without a reducer (the gloo twin of the RCCL test in
+    tests/test_rccl_gpu.py)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from generative_recommenders_amd import data_parallel as dp
+
+    assert dp.init_from_env(backend="gloo", single_rank_group=True) == (0, 0, 1) and dist.is_initialized()
+    mk = lambda: torch.nn.Sequential(*[torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh()) for _ in range(3)])
+    torch.manual_seed(0)
+    model = mk()
+    torch.manual_seed(0)
+    ref = mk()
+    red = dp.GradientAllReducer(None, buckets=[layer.parameters() for layer in model], overlap=True, single_rank_collectives=True)
+    g = torch.Generator().manual_seed(5)
+    for step in range(6):
+        data = torch.randn(8, 8, generator=g)
+        for m in (model, ref):
+            for p in m.parameters():
+                p.grad = None
+        if step % 2:
+            with red.no_sync():
+                model(data[:4]).pow(2).sum().backward()
+            model(data[4:]).pow(2).sum().backward()
+            ref(data[:4]).pow(2).sum().backward()
+            ref(data[4:]).pow(2).sum().backward()
+        else:
+            model(data).pow(2).sum().backward()
+            ref(data).pow(2).sum().backward()
+        red.reduce()
+        for p, q in zip(model.parameters(), ref.parameters()):
+            assert torch.equal(p.grad, q.grad)
+    assert red._calls == 6
+    open(os.path.join(out_dir, "ok0"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_gloo_single_rank_group_runs_the_collectives(tmp_path):
+    port = 29450 + (os.getpid() % 100)
+    mp.spawn(_worker_single, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
+
+
 def test_nccl_refuses_more_ranks_than_devices(monkeypatch):
     """two ranks on one GPU must fail loudly at start-up, not hang in the first collective"""
     import pytest
