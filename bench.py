@@ -245,7 +245,7 @@ def attention_section(args, rank, world, device, telem=None):
         parity=parity,
         elapsed=elapsed, users=B, rows=L, total_rows=dp.sum_over_ranks(float(L), device), fwd_ms=fwd_ms, bwd_ms=bwd_ms,
         fwd_gbps=fwd_bytes / fwd_ms / 1e6, bwd_gbps=(bwd_bytes / bwd_ms / 1e6) if bwd_ms else 0.0,
-        both_gbps=(fwd_bytes + bwd_bytes) / (fwd_ms + bwd_ms) / 1e6, bwd_bytes=bwd_bytes, fwd_bytes=fwd_bytes,
+        both_gbps=(fwd_bytes + bwd_bytes) / (fwd_ms + bwd_ms) / 1e6, bwd_bytes=bwd_bytes, fwd_bytes=fwd_bytes, prewarm_steps=prewarm_steps,
         tflops=flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12, kernels=kernels, fwd_only=fwd_only,
         device_ms_per_step=fwd_ms + bwd_ms, step_spread=step_spread,
     )
@@ -901,7 +901,7 @@ def attach_traffic(res, args, att):
         res["roofline_fwd"]["traffic_source"] = dict(file="profiles/" + name, kernel=ent["fwd"].get("kernel"), **src)
 
 
-def selftest_dist(args, rank, world):
+def selftest_dist(args, rank, world, out):
     """the N-rank scaffolding without the kernels (CPU, gloo): barrier-bracketed timing, MAX over ranks, the all-reduce
     probe and the one-line JSON contract -- what tests/test_data_parallel.py runs with --gpus 2"""
     from generative_recommenders_amd import data_parallel as dp
@@ -924,10 +924,37 @@ def selftest_dist(args, rank, world):
            "selftest": True, "rccl": rccl_section(world, device, nbytes=1 << 20),
            "ranks_seen": int(dp.sum_over_ranks(1.0, device))}
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        out.emit(json.dumps(res))
+
+
+class _StdoutToStderr:
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints its version banner to stdout when the box
+    exports NCCL_DEBUG=VERSION (the GPU boxes of this build do), hipBLASLt and MIOpen have their own moods -- so for the whole run
+    file descriptor 1 points at stderr, and the line goes to the saved descriptor at the very end."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def emit(self, text):
+        sys.stdout.flush()
+        os.write(self.saved, (text + "\n").encode())
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def run(args):
+    with _StdoutToStderr() as out:
+        _run(args, out)
+
+
+def _run(args, out):
     from generative_recommenders_amd import data_parallel as dp
 
     if os.environ.get("HSTU_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit if the run stalls
@@ -939,7 +966,7 @@ def run(args):
         rank, local_rank, world = dp.init_from_env(backend="gloo")
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-        selftest_dist(args, rank, world)
+        selftest_dist(args, rank, world, out)
         if dist.is_initialized():
             dist.destroy_process_group()
         return
@@ -1045,7 +1072,7 @@ def run(args):
     if rank == 0 and cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        out.emit(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

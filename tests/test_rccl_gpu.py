@@ -43,16 +43,16 @@ def make():
 model, ref = make(), make()
 red = dp.GradientAllReducer(None, buckets=[l.parameters() for l in model._stu_layers], overlap=True, single_rank_collectives=True,
                             check_every=10)
-opt_m = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
-opt_r = torch.optim.SGD(ref.parameters(), lr=1e-2, momentum=0.9)
+opt_m = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9)
+opt_r = torch.optim.SGD(ref.parameters(), lr=1e-4, momentum=0.9)
 g = torch.Generator(device=dev).manual_seed(3)
-steps, max_diff, collectives = 50, 0.0, 0
+steps, unequal, finite = 50, 0, True
 for step in range(steps):
     lengths = torch.randint(1, N + 1, (12,), generator=g, device=dev)
     off = dp.local_offsets(lengths)
     L = int(off[-1])
     x = torch.randn(L, D, device=dev, dtype=torch.bfloat16, generator=g)
-    gy = torch.randn(L, D, device=dev, dtype=torch.bfloat16, generator=g)
+    gy = 0.1 * torch.randn(L, D, device=dev, dtype=torch.bfloat16, generator=g)
     half = L // 2
     def run(m, accumulate):
         for p in m.parameters():
@@ -71,8 +71,8 @@ for step in range(steps):
     run(ref, acc)
     for p, q in zip(model.parameters(), ref.parameters()):
         assert p.grad is not None and q.grad is not None
-        if not torch.equal(p.grad, q.grad):
-            max_diff = max(max_diff, float((p.grad.float() - q.grad.float()).abs().max()))
+        finite = finite and bool(torch.isfinite(p.grad).all()) and bool(torch.isfinite(q.grad).all())
+        unequal += 0 if torch.equal(p.grad, q.grad) else 1
     opt_m.step()
     opt_r.step()
 torch.cuda.synchronize()
@@ -82,7 +82,7 @@ t = torch.ones((22 << 20) // 4, device=dev)
 dist.all_reduce(t)
 torch.cuda.synchronize()
 ok = bool((t == 1).all())
-print("RESULT " + json.dumps({"max_grad_diff": max_diff, "params_equal": params_equal, "allreduce_identity": ok, "calls": red._calls,
+print("RESULT " + json.dumps({"unequal_grads": unequal, "finite": finite, "params_equal": params_equal, "allreduce_identity": ok, "calls": red._calls,
                               "backend": info["backend"], "rccl_version": info.get("rccl_version"), "steps": steps}))
 dist.destroy_process_group()
 '''
@@ -100,7 +100,7 @@ def test_one_rank_rccl_group_runs_the_reducer_bit_for_bit(tmp_path):
     assert line, r.stdout[-2000:]
     res = json.loads(line[-1][7:])
     assert res["backend"] == "nccl" and res["rccl_version"], res
-    assert res["max_grad_diff"] == 0.0 and res["params_equal"] and res["allreduce_identity"], res
+    assert res["finite"] and res["unequal_grads"] == 0 and res["params_equal"] and res["allreduce_identity"], res
     assert res["calls"] == res["steps"] == 50, res
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
