@@ -22,11 +22,10 @@ static int launch_bwd_fold_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
   }
+  // one persistent workgroup per CU (never more workgroups than problems: every workgroup reads its first problem's offsets)
   int grid = p.batch * p.heads;
-  if (FOLD_PERSIST) {
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-    if (grid > n_cu) grid = n_cu;
-  }
+  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  if (grid > n_cu) grid = n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), smem, st, bp, tmax);
   return check_launch("hstu_attn_bwd(fold)");
 }

@@ -164,7 +164,7 @@ HSTU_DEV void quad_problem(const HstuAttnBwdParams& bp, int tmax, int uh, char* 
                 do_rs = bp.do_row_stride * C::EB;
 
   const int len_max = 32 * tmax;
-  const bool dma_fast = FOLD_DMA_FAST && q_rs < (1 << 24) && k_rs < (1 << 24) && v_rs < (1 << 24) && do_rs < (1 << 24) &&
+  const bool dma_fast = q_rs < (1 << 24) && k_rs < (1 << 24) && v_rs < (1 << 24) && do_rs < (1 << 24) &&
                         (int64_t)len_max * q_rs < (1LL << 32) && (int64_t)len_max * k_rs < (1LL << 32) &&
                         (int64_t)len_max * v_rs < (1LL << 32) && (int64_t)len_max * do_rs < (1LL << 32);
   auto stage_dma = [&](int qt) {

@@ -33,6 +33,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define HSTU_DEV __device__ __forceinline__
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLOBAL_PTR(T, p) ((__attribute__((address_space(1))) T*)(uintptr_t)(p))   // (see gload16 / gstore16)
 
 // ---------------------------------------------------------------------------
 // element-type traits
@@ -185,6 +186,15 @@ HSTU_DEV typename Elem<T>::Frag lds_col_frag(const char* tile, int rowA, int row
 HSTU_DEV int64_t load_index(const void* p, int64_t i, int is64) {
   return is64 ? ((const int64_t*)p)[i] : (int64_t)((const int32_t*)p)[i];
 }
+// The same through the CONSTANT address space: with a wave-uniform index hipcc emits a scalar load (s_load, counted by lgkmcnt) instead
+// of a vector load + v_readfirstlane + s_waitcnt vmcnt(0).  The difference matters in the persistent kernels: a vmcnt(0) at the top of
+// a problem waits for every LDS-DMA request and every store the previous problem's tail left in flight.  Legal for arrays the kernel
+// only reads (offsets, targets, launch order): the scalar cache is not coherent with this kernel's own vector stores.
+HSTU_DEV int64_t sload_index(const void* p, int64_t i, int is64) {
+  typedef const __attribute__((address_space(4))) int64_t* c64;
+  typedef const __attribute__((address_space(4))) int32_t* c32;
+  return is64 ? ((c64)(uintptr_t)p)[i] : (int64_t)((c32)(uintptr_t)p)[i];
+}
 
 // ---------------------------------------------------------------------------
 // mask algebra (reference: ops/pytorch/pt_hstu_attention.py:32-84)
@@ -259,6 +269,8 @@ struct MaskCtx {
   }
 };
 
+// SCALAR: the user index is wave-uniform and num_targets read-only -> sload_index
+template <bool SCALAR = false>
 HSTU_DEV MaskCtx make_mask_ctx(const HstuAttnParams& p, int b, int len) {
   MaskCtx m;
   m.len = len;
@@ -268,7 +280,7 @@ HSTU_DEV MaskCtx make_mask_ctx(const HstuAttnParams& p, int b, int len) {
   m.has_targets = p.num_targets != nullptr;
   int max_id = len;
   if (m.ctx > 0) max_id = max_id - m.ctx + 1;
-  if (m.has_targets) max_id -= (int)load_index(p.num_targets, b, p.targets_dtype);
+  if (m.has_targets) max_id -= (int)(SCALAR ? sload_index(p.num_targets, b, p.targets_dtype) : load_index(p.num_targets, b, p.targets_dtype));
   m.max_id = max_id;
   m.simple = (!m.has_targets) && m.win == 0 && m.ctx == 0;
   return m;
@@ -416,25 +428,26 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
   char* lt32 = ltime + (8 * n + 15) / 16 * 16;
   if (!user_only) {
     for (int i = tid; i < 32; i += nthreads) *LDS_PTR(float, lds + 4 * i) = 0.f;
-    for (int i = tid; i < 2 * n - 1; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = p.pos_w[i];
+    for (int i = tid; i < 2 * n - 1; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = GLOBAL_PTR(const float, p.pos_w)[i];
     for (int i = 2 * n - 1 + tid; i < (int)(lts - lpos) / 4; i += nthreads) *LDS_PTR(float, lpos + 4 * i) = 0.f;
   }
   if (ts_row) {
     if (!user_only)
-      for (int i = tid; i <= p.num_buckets; i += nthreads) *LDS_PTR(float, lts + 4 * i) = p.ts_w[i];
-    const int64_t t0 = ts_row[0];
+      for (int i = tid; i <= p.num_buckets; i += nthreads) *LDS_PTR(float, lts + 4 * i) = GLOBAL_PTR(const float, p.ts_w)[i];
+    const auto* const ts_row_g = GLOBAL_PTR(const int64_t, ts_row);
+    const int64_t t0 = ts_row_g[0];
     bool big = false;
     for (int i = tid; i < n; i += nthreads) {
-      const int64_t t = ts_row[i], o = t - t0;
+      const int64_t t = ts_row_g[i], o = t - t0;
       *LDS_PTR(int64_t, ltime + 8 * i) = t;
       *LDS_PTR(int, lt32 + 4 * i) = (int)o;
       big = big || o >= (1LL << 30) || o <= -(1LL << 30);
     }
     const int npad = (n + 32 + 3) / 4 * 4;
-    const int last = (int)(ts_row[n - 1] - t0);
+    const int last = (int)(ts_row_g[n - 1] - t0);
     for (int i = n + tid; i < npad; i += nthreads) *LDS_PTR(int, lt32 + 4 * i) = last;          // padding: see t32_at
     for (int i = tid; i < npad; i += nthreads)                                                  // shifted copy: entry i = t[i+1]
-      *LDS_PTR(int, lt32 + 4 * (npad + i)) = i + 1 < n ? (int)(ts_row[i + 1] - t0) : last;
+      *LDS_PTR(int, lt32 + 4 * (npad + i)) = i + 1 < n ? (int)(ts_row_g[i + 1] - t0) : last;
     const bool wave_big = __builtin_amdgcn_ballot_w64(big) != 0;
     if ((tid & 63) == 0) *LDS_PTR(int, lt32 + 4 * (2 * npad + (tid >> 6))) = wave_big ? 1 : 0;
   } else if (!user_only) {
@@ -446,6 +459,9 @@ HSTU_DEV BiasCtx stage_bias_tables(const HstuAttnParams& p, int b, char* lds, in
 
 // user of workgroup slot `slot` (HstuAttnParams::user_order: heavy-first launch order for long-tailed batches)
 HSTU_DEV int user_of_slot(const HstuAttnParams& p, int slot) { return p.user_order ? p.user_order[slot] : slot; }
+HSTU_DEV int user_of_slot_s(const HstuAttnParams& p, int slot) {      // (wave-uniform slot: scalar load, see sload_index)
+  return p.user_order ? (int)sload_index(p.user_order, slot, 0) : slot;
+}
 
 // 1/N, or the caller's device-side replacement for it (HstuAttnParams::attn_scale: the reference's attn_scale[0])
 HSTU_DEV float attn_scale_of(const HstuAttnParams& p) { return p.attn_scale ? *p.attn_scale : p.scale; }
@@ -483,11 +499,13 @@ struct TraceCtx { unsigned long long* p; bool on; int i; };
 // iterations end with atomics (the multi-key-block backward) that is a full L2 round trip per step.
 HSTU_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// 16-byte global load / store helpers
-HSTU_DEV u32x4 gload16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-HSTU_DEV void gstore16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+// 16-byte global load / store helpers.  The pointers are cast to the GLOBAL address space: a pointer hipcc cannot trace back to a
+// kernel argument (one re-read from the kernel-argument segment inside a persistent loop, see hstu_attn_bwd_fold.cuh) would otherwise
+// be accessed with flat_* instructions, which also occupy the LDS counter.
+HSTU_DEV u32x4 gload16(const void* p) { return *GLOBAL_PTR(const u32x4, p); }
+HSTU_DEV void gstore16(void* p, u32x4 v) { *GLOBAL_PTR(u32x4, p) = v; }
 // streaming variant (written once, not read again by this kernel).  Measured: forward 1.40 -> 1.38 ms; the folded
 // backward gets SLOWER with it (3.08 -> 3.15 ms), so only the forward's output rows use it.
-HSTU_DEV void gstore16_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
+HSTU_DEV void gstore16_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, GLOBAL_PTR(u32x4, p)); }
 
 }  // namespace hstu
