@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../generative_recommenders_amd/csrc"
 mkdir -p build_trace
-for f in capi attn_misc attn_bf16 attn_bias_bf16 attn_fold_bf16 attn_solo_bf16 jagged_ops norm_ops position_ops embedding_grad loss_ops; do
+for f in capi attn_misc attn_bf16 attn_bias_bf16 attn_fold_bf16 attn_solo_bf16 jagged_ops norm_ops ln_linear aux_ops position_ops embedding_grad loss_ops; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHSTU_TRACE $HSTU_EXTRA -I. -I../../include -c $f.hip -o build_trace/$f.o &
 done
 wait

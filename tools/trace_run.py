@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from generative_recommenders_amd import _lib as L
-L.LIB_PATH = os.path.join(ROOT, "tests", "probe", "libhstu_trace.so")
+L.LIB_PATH = os.environ.get("HSTU_TRACE_LIB", os.path.join(ROOT, "tests", "probe", "libhstu_trace.so"))
 from generative_recommenders_amd.ops import _launch
 
 dev = "cuda"
