@@ -10,6 +10,7 @@ int launch_attn_bwd_bf16(const HstuAttnBwdParams& p, hipStream_t st) {
   if (attn_solo_applicable(p.fwd, true)) return launch_attn_bwd_solo_bf16(p, st);
   if (attn_solo_bias_applicable(p.fwd, true)) return launch_attn_bwd_solo_bias_bf16(p, st);
   if (attn_bwd_fold_applicable(p)) return launch_attn_bwd_fold_bf16(p, st);
+  if (attn_bwd_long_applicable(p)) return launch_attn_bwd_long_bf16(p, st);
   return p.fwd.pos_w ? launch_attn_bwd_bias_bf16(p, st) : launch_bwd_dtype<bf16_t>(p, st);
 }
 int attn_bwd_tiles_bf16(int dqk, int dv, int n, int extra_lds) { return bwd_tiles_dtype<bf16_t>(dqk, dv, n, extra_lds); }

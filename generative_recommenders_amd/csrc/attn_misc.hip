@@ -33,6 +33,18 @@ bool attn_bwd_fold_applicable(const HstuAttnBwdParams& bp) {
   return (p.max_seq_len + 31) / 32 <= 7;
 }
 
+// The two-kernel backward for long sequences (hstu_attn_bwd_long.cuh): what the folded schedule does not take for length only.
+bool attn_bwd_long_applicable(const HstuAttnBwdParams& bp) {
+  const HstuAttnParams& p = bp.fwd;
+  static const bool enabled = [] { const char* e = getenv("HSTU_BWD_LONG"); return !(e && e[0] == '0'); }();
+  if (!enabled) return false;
+  if (p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.contextual_seq_len > 0 || p.delta_q != 0) return false;
+  if (p.dqk != p.dv || (p.dqk != 128 && p.dqk != 64)) return false;
+  const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;          // masks ride on the S accumulator's start value (-1e30)
+  if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
+  return (p.max_seq_len + 31) / 32 > 7;
+}
+
 bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {
   static const bool enabled = [] { const char* e = getenv("HSTU_SOLO"); return !(e && e[0] == '0'); }();
   if (!enabled || p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.delta_q != 0) return false;
@@ -117,6 +129,7 @@ int attn_kernel_name(const HstuAttnParams& p, const HstuAttnBwdParams* bwd, char
   else if (attn_solo_bias_applicable(p, bwd != nullptr)) snprintf(buf, len, "hstu_attn_%s_solo_bias_kernel<%s>", bwd ? "bwd" : "fwd", dt);
   else if (bwd && attn_bwd_quad_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_quad_kernel<%s,%d>", dt, a);
   else if (bwd && attn_bwd_fold_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_kernel<%s,%d,%d>", dt, a, v);
+  else if (bwd && attn_bwd_long_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_dkv_kernel<%s,%d>+hstu_attn_bwd_dq_kernel<%s,%d>", dt, a, dt, a);
   else if (bwd && attn_bwd_fold_bias_applicable(*bwd)) snprintf(buf, len, "hstu_attn_bwd_fold_bias_kernel<%s,64>", dt);
   else if (!bwd && attn_fwd_head_loop_applicable(p, attn_fwd_ring_bytes(p.dtype == HSTU_DTYPE_F32 ? 4 : 2, a, v), nullptr, nullptr))
     snprintf(buf, len, "hstu_attn_fwd_kernel<%s,%d,%d,bias,heads>", dt, a, v);

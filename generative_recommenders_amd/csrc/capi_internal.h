@@ -25,6 +25,11 @@ int launch_attn_bwd_bias_f32(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_bf16(const HstuAttnBwdParams& p, hipStream_t st);
 int launch_attn_bwd_fold_f16(const HstuAttnBwdParams& p, hipStream_t st);
 bool attn_bwd_fold_applicable(const HstuAttnBwdParams& p);
+// long sequences (more than one key block), 16-bit I/O, no bias, no contextual rows: dK / dV kernel + dQ kernel, no atomics, no
+// workspace (hstu_attn_bwd_long.cuh; HSTU_BWD_LONG=0: the general kernel, A/B measurements)
+int launch_attn_bwd_long_bf16(const HstuAttnBwdParams& p, hipStream_t st);
+int launch_attn_bwd_long_f16(const HstuAttnBwdParams& p, hipStream_t st);
+bool attn_bwd_long_applicable(const HstuAttnBwdParams& p);
 // short sequences (max_seq_len <= 64, head dims <= 32, 16-bit I/O): one wave per (user, head) (hstu_attn_solo.cuh; HSTU_SOLO=0 disables)
 int launch_attn_fwd_solo_bf16(const HstuAttnParams& p, hipStream_t st);
 int launch_attn_fwd_solo_f16(const HstuAttnParams& p, hipStream_t st);

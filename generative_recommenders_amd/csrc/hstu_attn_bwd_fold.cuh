@@ -109,7 +109,8 @@ struct FoldBias {
 };
 
 // One (query tile i0, key tile k0) pair on the owner wave: S, dP, P', dS', dV += , dK +=, publish dS'.
-template <typename T, int DQK, int DV, typename BX = FoldNoBias>
+// PUBLISH = false (the long-sequence dK / dV kernel, hstu_attn_bwd_long.cuh: dQ comes from a kernel of its own): dS' stays in registers.
+template <typename T, int DQK, int DV, typename BX = FoldNoBias, bool PUBLISH = true>
 HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char* __restrict__ Kw, const char* __restrict__ Vw,
                         const char* __restrict__ Qs, const char* __restrict__ dOs, char* __restrict__ myds, int i0, int k0, f32x16 (&dk_acc)[DQK / 32],
                         f32x16 (&dv_acc)[DV / 32], int lane, int dmvm, BX& bx HSTU_TRACE_ARG) {
@@ -308,7 +309,7 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
   }
   // publish dS' as [key = n32][q]: this lane holds q = 4 hf + 8 rq + (0..3) = chunk hf + 2 rq
 #pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
+  for (int rq = 0; PUBLISH && rq < 4; ++rq) {
     const u32x4 w = __builtin_bit_cast(u32x4, dsb[rq >> 1].v);
     u32x2 v2 = {w[2 * (rq & 1)], w[2 * (rq & 1) + 1]};
     *LDS_PTR(u32x2, myds + fold_ds_off(n32, hf + 2 * rq)) = v2;
