@@ -246,7 +246,7 @@ def attention_section(args, rank, world, device, telem=None):
         elapsed=elapsed, users=B, rows=L, total_rows=dp.sum_over_ranks(float(L), device), fwd_ms=fwd_ms, bwd_ms=bwd_ms,
         fwd_gbps=fwd_bytes / fwd_ms / 1e6, bwd_gbps=(bwd_bytes / bwd_ms / 1e6) if bwd_ms else 0.0,
         both_gbps=(fwd_bytes + bwd_bytes) / (fwd_ms + bwd_ms) / 1e6, bwd_bytes=bwd_bytes, fwd_bytes=fwd_bytes, prewarm_steps=prewarm_steps,
-        tflops=flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12, kernels=kernels, fwd_only=fwd_only,
+        tflops=flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12, flops=flops, kernels=kernels, fwd_only=fwd_only,
         device_ms_per_step=fwd_ms + bwd_ms, step_spread=step_spread,
     )
 
@@ -272,6 +272,17 @@ def rooflines(att, workload):
     if workload == "C5":
         fwd = dict(main)
     both = {"achieved": att["both_gbps"], "unit": "GB/s", "frac": att["both_gbps"] / HBM_PEAK_GBPS, "tflops_causal_model": att["tflops"]}
+    if workload == "L2048":
+        # long sequences: ~900 FLOP per byte, far over the ridge: bound = the matrix pipes.  Causal FLOP model, 2 d L^2 forward
+        # (two GEMMs over the triangle) + 5 d L^2 backward per user and head; the backward EXECUTES 7 d L^2 (the two-kernel schedule
+        # recomputes S and dP in its dQ kernel: csrc/hstu_attn_bwd_long.cuh) -- the fraction prices the model's FLOPs, not those
+        tf_f = att["flops"] * 2.0 / 7.0 / (att["fwd_ms"] * 1e-3) / 1e12
+        tf_b = att["flops"] * 5.0 / 7.0 / (att["bwd_ms"] * 1e-3) / 1e12
+        main = {"bound": "mfma", "kernel": att["kernels"]["bwd"], "achieved": tf_b, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_b / MFMA_PEAK_TFLOPS,
+                "traffic": None, "algorithmic_bytes_per_launch": att["bwd_bytes"], "avg_launch_ms": att["bwd_ms"]}
+        fwd = {"bound": "mfma", "kernel": att["kernels"]["fwd"], "achieved": tf_f, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_f / MFMA_PEAK_TFLOPS,
+               "algorithmic_bytes_per_launch": att["fwd_bytes"], "avg_launch_ms": att["fwd_ms"]}
+        both = {"achieved": att["tflops"], "unit": "TFLOP/s", "frac": att["tflops"] / MFMA_PEAK_TFLOPS, "tflops_causal_model": att["tflops"]}
     return main, fwd, both
 
 

@@ -38,11 +38,12 @@ bool attn_bwd_long_applicable(const HstuAttnBwdParams& bp) {
   const HstuAttnParams& p = bp.fwd;
   static const bool enabled = [] { const char* e = getenv("HSTU_BWD_LONG"); return !(e && e[0] == '0'); }();
   if (!enabled) return false;
-  if (p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.contextual_seq_len > 0 || p.delta_q != 0) return false;
+  if (p.dtype == HSTU_DTYPE_F32 || p.pos_w || p.delta_q != 0) return false;
   if (p.dqk != p.dv || (p.dqk != 128 && p.dqk != 64)) return false;
   const float aa = p.alpha < 0.f ? -p.alpha : p.alpha;          // masks ride on the S accumulator's start value (-1e30)
   if (!(aa == 0.f || (aa > 1e-20f && aa < 1e6f))) return false;
-  return (p.max_seq_len + 31) / 32 > 7;
+  // longer than the folded schedule takes -- or contextual rows, which it does not take at any length
+  return (p.max_seq_len + 31) / 32 > 7 || (p.contextual_seq_len > 0 && p.max_seq_len > 64);
 }
 
 bool attn_solo_applicable(const HstuAttnParams& p, bool backward) {
@@ -202,6 +203,9 @@ int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies) {
 
 size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& bp) {
   const HstuAttnParams& p = bp.fwd;
+  // the short-sequence schedules and the two-kernel long backward add nothing in memory (the research-path kernels keep their
+  // histogram rows: p.pos_w below)
+  if (!p.pos_w && (attn_solo_applicable(p, true) || attn_bwd_fold_applicable(bp) || attn_bwd_long_applicable(bp))) return 0;
   const int hist = attn_bwd_bias_lds(p, nullptr);
   const int nw = attn_bwd_tiles_per_block(p.dtype, p.dqk, p.dv, p.max_seq_len, hist);
   if (nw <= 0) return 0;

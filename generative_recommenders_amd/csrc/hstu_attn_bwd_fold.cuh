@@ -110,7 +110,8 @@ struct FoldBias {
 
 // One (query tile i0, key tile k0) pair on the owner wave: S, dP, P', dS', dV += , dK +=, publish dS'.
 // PUBLISH = false (the long-sequence dK / dV kernel, hstu_attn_bwd_long.cuh: dQ comes from a kernel of its own): dS' stays in registers.
-template <typename T, int DQK, int DV, typename BX = FoldNoBias, bool PUBLISH = true>
+// CTXM (that kernel's instantiation for contextual_seq_len > 0): partly valid tiles take the general predicate, by compares.
+template <typename T, int DQK, int DV, typename BX = FoldNoBias, bool PUBLISH = true, bool CTXM = false>
 HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char* __restrict__ Kw, const char* __restrict__ Vw,
                         const char* __restrict__ Qs, const char* __restrict__ dOs, char* __restrict__ myds, int i0, int k0, f32x16 (&dk_acc)[DQK / 32],
                         f32x16 (&dv_acc)[DV / 32], int lane, int dmvm, BX& bx HSTU_TRACE_ARG) {
@@ -146,10 +147,23 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
     if (mode == 1) km = ((k0 == i0) ? dmvm : -1) & ((i0 + 32 > len) ? (dmvm >> 16) : -1);
     if (mode == 2) {
       km = 0;
+      bool ctx_done = false;
+      if constexpr (CTXM) {           // (the long-sequence dK / dV kernel also takes contextual rows; the folded kernels never see them)
+        if (mc.ctx > 0) {             // wave-uniform: the general predicate by compares
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-        km |= (mc.keep_bits_noctx(qi, key, key_id) & key_bits & 1) << r;
+          for (int r = 0; r < 16; ++r) {
+            const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            km |= (((qi < len) & key_ok & mc.valid_ids(qi, key, mc.id_of(qi), key_id)) ? 1 : 0) << r;
+          }
+          ctx_done = true;
+        }
+      }
+      if (!ctx_done) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = i0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          km |= (mc.keep_bits_noctx(qi, key, key_id) & key_bits & 1) << r;
+        }
       }
     }
     const unsigned nk = ~(unsigned)km;

@@ -29,8 +29,18 @@
 
 namespace hstu {
 
-constexpr int kLongNW = 7;        // key tiles (owner waves) per block of the dK / dV kernel
-constexpr int kLongStages = 3;    // its Q / dO ring
+#ifndef LONG_NW
+#define LONG_NW 7
+#endif
+#ifndef LONG_STAGES
+#define LONG_STAGES 3
+#endif
+#ifndef LONG_LAUNDER
+#define LONG_LAUNDER 0   // 1: lane id laundered in front of the pair (LDS offsets recomputed per pair: 214 instead of 233 registers, 3-5 % slower)
+#endif
+constexpr int kLongNW = LONG_NW;            // key tiles (owner waves) per block of the dK / dV kernel
+constexpr int kLongStages = LONG_STAGES;    // its Q / dO ring
+static_assert(kLongNW <= kBwdWaves && kLongStages >= 2 && (kLongNW + kLongStages) * 16 <= 160, "LDS");
 
 template <typename T, int D>
 struct LongCfg {
@@ -41,7 +51,8 @@ struct LongCfg {
 // -------------------------------------------------------------------------------------------------------------------------------
 // dK / dV
 // -------------------------------------------------------------------------------------------------------------------------------
-template <typename T, int D>
+// CTX: the instantiation for contextual_seq_len > 0 (query tiles with contextual rows in front of the block's own; general predicate)
+template <typename T, int D, bool CTX = false>
 __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void hstu_attn_bwd_dkv_kernel(const HstuAttnBwdParams bp, int nkb) {
   using C = BwdCfg<T, D, D>;
   static_assert(C::EB == 2, "16-bit I/O");
@@ -68,11 +79,14 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   const MaskCtx mc = make_mask_ctx(p, b, len);
   const int nt = (len + 31) >> 5;
   const int nw = min(kLongNW, nt - kt0);      // key tiles of this block
-  // query tiles that can see a key of the block: from the block's first tile on (causal; no contextual rows here), up to the reach
-  // of the attention window when there is one and nothing lifts it (min_full_attn_seq_len, target rows: their ids are clamped)
-  const int it_lo = kt0;
+  // query tiles that can see a key of the block: from the block's first tile on (causal), up to the reach of the attention window
+  // when there is one and nothing lifts it (min_full_attn_seq_len, target rows: their ids are clamped, contextual rows: ids shifted);
+  // in front of them the tiles that hold contextual rows (id 0: they see every key).  Step j of the loop is query tile tile_of(j).
   int it_hi = nt;
-  if (mc.win > 0 && mc.full == 0 && !mc.has_targets) it_hi = min(nt, ((32 * (kt0 + nw) - 1 + mc.win) >> 5) + 1);
+  if (mc.win > 0 && mc.full == 0 && !mc.has_targets && mc.ctx == 0) it_hi = min(nt, ((32 * (kt0 + nw) - 1 + mc.win) >> 5) + 1);
+  const int n_pre = (CTX && mc.ctx > 0) ? min((mc.ctx + 31) >> 5, kt0) : 0;
+  const int n_steps = n_pre + it_hi - kt0;
+  auto tile_of = [&](int j) { return (CTX && j < n_pre) ? j : kt0 + (j - n_pre); };
 
   const char* qbase = (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * C::EB;
   const char* kbase = (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * C::EB;
@@ -99,7 +113,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     fold_tile_dma<T, D>(dst, kbase, k_rs, 32 * (kt0 + t), len, wave, lane, dma_fast);
     fold_tile_dma<T, D>(dst + C::KT, vbase, v_rs, 32 * (kt0 + t), len, wave, lane, dma_fast);
   }
-  for (int i = 0; i < kLongStages - 1 && it_lo + i < it_hi; ++i) stage_dma(it_lo + i, i);
+  for (int j = 0; j < kLongStages - 1 && j < n_steps; ++j) stage_dma(tile_of(j), j);
 
   f32x16 dk_acc[C::DBQ], dv_acc[C::DBV];
 #pragma unroll
@@ -125,22 +139,26 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   FoldNoBias nb;
   HSTU_TRACE_DECL(nullptr, false);
 
-  for (int it = it_lo; it < it_hi; ++it) {
-    const int slot = (it - it_lo) % kLongStages;
-    // tile `it` has landed once only the tile requested after it is pending
-    if (it + 1 < it_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  for (int j = 0; j < n_steps; ++j) {
+    const int it = tile_of(j);
+    const int slot = j % kLongStages;
+    // the tile of step j has landed once only the tiles requested after it are pending
+    const int newer = min(kLongStages - 2, n_steps - 1 - j);      // tiles requested after this one so far
+    static_assert(kLongStages <= 4, "counted waits below");
+    if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave's chunks of tile `it` (first time: of the K / V block) landed; the stage of tile it - 1 is free
+    __builtin_amdgcn_s_barrier();   // every wave's chunks of this tile (first time: of the K / V block) landed; the stage of the step before is free
     asm volatile("" ::: "memory");
-    if (it + kLongStages - 1 < it_hi) stage_dma(it + kLongStages - 1, (slot + kLongStages - 1) % kLongStages);
-    if (owner && mc.pair_may_be_active(32 * it, 32, 32 * kt, 32)) {
+    if (j + kLongStages - 1 < n_steps) stage_dma(tile_of(j + kLongStages - 1), (slot + kLongStages - 1) % kLongStages);
+    if (owner && (mc.simple ? it >= kt : mc.pair_may_be_active(32 * it, 32, 32 * kt, 32))) {
       const char* Kw = smem + wave * C::PAIR;
       const char* st = ring + slot * C::PAIR;
-      // (the lane id is laundered: LDS offsets derived from it are recomputed here instead of living across the loop next to the
-      // 128 accumulator registers -- hstu_attn_bwd_fold.cuh)
+      // (LONG_LAUNDER: the lane id laundered, LDS offsets derived from it recomputed per pair instead of living across the loop --
+      // what the folded kernel needs next to its dQ phase; here they fit: 233 registers, 3-5 % faster)
       int lane1 = lane;
-      asm volatile("" : "+v"(lane1));
-      fold_pair_x<T, D, D, FoldNoBias, false>(p, mc, Kw, Kw + C::KT, st, st + C::KT, nullptr, 32 * it, 32 * kt, dk_acc, dv_acc, lane1, dmvm, nb HSTU_TRACE_PASS);
+      if (LONG_LAUNDER) asm volatile("" : "+v"(lane1));
+      fold_pair_x<T, D, D, FoldNoBias, false, CTX>(p, mc, Kw, Kw + C::KT, st, st + C::KT, nullptr, 32 * it, 32 * kt, dk_acc, dv_acc, lane1, dmvm, nb HSTU_TRACE_PASS);
     }
   }
   // ---- epilogue: every owner parks its two tiles over its own K / V tile (nobody else reads them in this kernel) and copies the
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
 // -------------------------------------------------------------------------------------------------------------------------------
 // dQ
 // -------------------------------------------------------------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, bool CTX = false>
 __global__ __launch_bounds__(kFwdThreads, 2) void hstu_attn_bwd_dq_kernel(const HstuAttnBwdParams bp, int nqb) {
   using C = FwdCfg<T, D, D>;
   using E = Elem<T>;
@@ -198,13 +216,15 @@ __global__ __launch_bounds__(kFwdThreads, 2) void hstu_attn_bwd_dq_kernel(const 
   const int qi = r0 + n32;                     // this lane's query row
   const bool row_ok = qi < len;
 
-  // key range of the workgroup (conservative; the element mask is exact)
+  // key range of the workgroup (conservative; the element mask is exact); contextual rows (id 0) see every key
   const int i_last = min(q0 + kFwdRowsPerBlock, len) - 1;
-  const int kv_hi = min(len, i_last + 1);
+  const bool ctx_rows = CTX && mc.ctx > 0 && q0 < mc.ctx;
+  const int kv_hi = ctx_rows ? len : min(len, i_last + 1);
   int kv_lo = 0;
-  if (mc.win > 0 && mc.full == 0) {
+  if (mc.win > 0 && mc.full == 0 && !ctx_rows) {
     const int x = mc.id_of(q0) - mc.win;
-    kv_lo = x <= 0 ? 0 : ((x >> 5) << 5);
+    const int pos = x <= 0 ? 0 : ((CTX && mc.ctx > 0) ? x + mc.ctx - 1 : x);
+    kv_lo = (pos >> 5) << 5;
   }
   const int ntiles = (kv_hi - kv_lo + 31) >> 5;
 
@@ -275,8 +295,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void hstu_attn_bwd_dq_kernel(const 
     const char* Vt = Kt + C::KT;
     // mode (wave-uniform): 0 no mask, 4 plain causal (the only partly masked tile is the aligned diagonal one: a lane-constant
     // pattern, put into S itself -- a masked element is -1e30, alpha S hugely negative, exp2 gives +inf, the sigmoid exactly 0 and
-    // dS' = dP * 0), 3 targets / window by integer arithmetic
-    const int mode = tile_full ? 0 : (mc.simple ? 4 : 3);
+    // dS' = dP * 0), 3 targets / window by integer arithmetic, 2 contextual rows: the general predicate by compares
+    const int mode = tile_full ? 0 : (mc.simple ? 4 : ((!CTX || mc.ctx == 0) ? 3 : 2));
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -324,6 +344,16 @@ __global__ __launch_bounds__(kFwdThreads, 2) void hstu_attn_bwd_dq_kernel(const 
           const int idj = mc.has_targets ? min(key, mc.max_id) : key;
           const int keep = mc.keep_bits_row(i_eff, idi, key, idj) & ((key - len) >> 31);
           dsv[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, dsv[j]) & keep);
+        }
+      }
+      if (CTX && mode == 2) {
+        const int qi_id = mc.id_of(qi);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * h8 + j;
+          const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          const bool ok = row_ok & (key < len) & mc.valid_ids(qi, key, qi_id, mc.id_of(key));
+          dsv[j] = ok ? dsv[j] : 0.f;
         }
       }
       dsb[h8] = E::pack8(dsv);
@@ -375,7 +405,7 @@ static int launch_bwd_long_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   {
     const int nkb = (tmax + kLongNW - 1) / kLongNW;
     const int smem = LongCfg<T, D>::smem_dkv();
-    auto kern = hstu_attn_bwd_dkv_kernel<T, D>;
+    auto kern = p.contextual_seq_len > 0 ? hstu_attn_bwd_dkv_kernel<T, D, true> : hstu_attn_bwd_dkv_kernel<T, D, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd(long): cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(groups * 8 * nkb), dim3(kBwdThreads), smem, st, bp, nkb);
@@ -384,7 +414,7 @@ static int launch_bwd_long_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   {
     using C = FwdCfg<T, D, D>;
     const int nqb = (p.max_seq_len + kFwdRowsPerBlock - 1) / kFwdRowsPerBlock;
-    auto kern = hstu_attn_bwd_dq_kernel<T, D>;
+    auto kern = p.contextual_seq_len > 0 ? hstu_attn_bwd_dq_kernel<T, D, true> : hstu_attn_bwd_dq_kernel<T, D, false>;
     hipLaunchKernelGGL(kern, dim3(groups * 8 * nqb), dim3(kFwdThreads), C::SMEM, st, bp, nqb);
     return check_launch("hstu_attn_bwd(long, dq)");
   }

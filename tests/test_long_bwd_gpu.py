@@ -35,7 +35,8 @@ def _run(N, H, d, dtype, lengths, seed, **kw):
         okw["num_targets"] = np.minimum(rng.integers(0, 30, size=B), lengths)
     tkw = {n: (torch.from_numpy(x.astype(np.int64)).to(DEV) if isinstance(x, np.ndarray) else x) for n, x in okw.items()}
     alpha = d ** -0.5
-    name = _launch.attn_bwd_kernel_name(dtype, d, d, N, heads=H, alpha=alpha, max_attn_len=okw.get("max_attn_len", 0))
+    name = _launch.attn_bwd_kernel_name(dtype, d, d, N, heads=H, alpha=alpha, max_attn_len=okw.get("max_attn_len", 0),
+                                        contextual_seq_len=okw.get("contextual_seq_len", 0))
     assert name.startswith("hstu_attn_bwd_dkv_kernel"), name
     outs = []
     for _ in range(2):
@@ -75,11 +76,14 @@ def test_plain_causal(N, d, dtype):
 
 
 @pytest.mark.parametrize("d", [128, 64])
-@pytest.mark.parametrize("mask", ["targets", "window", "window_full", "window_targets"])
+@pytest.mark.parametrize("mask", ["targets", "window", "window_full", "window_targets", "ctx", "ctx_long", "ctx_window_targets"])
 def test_masks(mask, d):
     N = 520
     kw = {"targets": {"targets": True}, "window": {"max_attn_len": 100}, "window_full": {"max_attn_len": 64, "min_full_attn_seq_len": 40},
-          "window_targets": {"max_attn_len": 150, "targets": True}}[mask]
+          "window_targets": {"max_attn_len": 150, "targets": True},
+          # contextual rows (id 0: they see every non-target key): their query tiles run in front of every key block's own
+          "ctx": {"contextual_seq_len": 5}, "ctx_long": {"contextual_seq_len": 40},
+          "ctx_window_targets": {"contextual_seq_len": 7, "max_attn_len": 90, "targets": True}}[mask]
     _run(N, 2, d, torch.bfloat16, [N, 300, 0, 519, 226, 97], seed=17 + d, **kw)
 
 
@@ -91,3 +95,10 @@ def test_long_rows_1500_many_blocks():
 def test_window_much_shorter_than_the_sequence():
     """the dK/dV kernel stops its query tiles at the window's reach, the dQ kernel starts its key tiles there"""
     _run(1200, 2, 128, torch.bfloat16, [1200, 1000, 333], seed=6, max_attn_len=70)
+
+
+@pytest.mark.parametrize("N", [100, 200])
+def test_contextual_rows_at_short_lengths_take_this_path(N):
+    """the folded schedules refuse contextual rows: from 65 rows on such batches run the two kernels (one key block)"""
+    _run(N, 2, 128, torch.bfloat16, [N, N - 1, 0, 70, 33, 3], seed=9, contextual_seq_len=6)
+    _run(N, 2, 64, torch.float16, [N, 64, 65], seed=10, contextual_seq_len=3, targets=True)

@@ -81,7 +81,14 @@ def test_the_headline_backward_is_the_folded_kernel():
     assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 200).startswith(want)
     assert _launch.attn_bwd_kernel_name(torch.bfloat16, 64, 64, 200).startswith("hstu_attn_bwd_quad_kernel")
     assert _launch.attn_bwd_kernel_name(torch.float32, 128, 128, 200).startswith("hstu_attn_bwd_kernel")
-    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 256).startswith("hstu_attn_bwd_kernel")
+    # more than one key block (the reference's benchmark sweep, 2^8 .. 2^12): the two-kernel long backward; fp32 I/O: the general kernel
+    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 256) == "hstu_attn_bwd_dkv_kernel<bf16,128>+hstu_attn_bwd_dq_kernel<bf16,128>"
+    assert _launch.attn_bwd_kernel_name(torch.float16, 64, 64, 2048).startswith("hstu_attn_bwd_dkv_kernel<f16,64>")
+    assert _launch.attn_bwd_kernel_name(torch.float32, 128, 128, 256).startswith("hstu_attn_bwd_kernel")
+    # contextual rows: the folded schedules do not take them, the two-kernel path does (from 65 rows on)
+    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 256, contextual_seq_len=4).startswith("hstu_attn_bwd_dkv_kernel")
+    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 200, contextual_seq_len=4).startswith("hstu_attn_bwd_dkv_kernel")
+    assert _launch.attn_bwd_kernel_name(torch.bfloat16, 128, 128, 64, contextual_seq_len=4).startswith("hstu_attn_bwd_kernel")
 
 
 def test_bench_projection_section_calls_the_products_gemms():

@@ -65,12 +65,19 @@ def main():
             names["bwd"] = _launch.attn_bwd_kernel_name(torch.bfloat16, d, d, n, heads=h, alpha=d ** -0.5, with_bias=bias)
         ent = {"source": {"workload": wl, "users_per_gpu": users, "head_dim": d, "heads": h, "dtype": "bf16"}, "sources_sha256": sha}
         for side, full in names.items():
-            short = full.split("<")[0]
-            cand = [k for k in summ if k == short] or [k for k in summ if short.startswith(k) or k.startswith(short)]
-            if not cand or "FETCH_SIZE" not in summ[cand[0]] or "WRITE_SIZE" not in summ[cand[0]]:
-                print(f"{spec}: no FETCH_SIZE / WRITE_SIZE for {full} (sections: {sorted(summ)})", file=sys.stderr)
+            # ("a<..>+b<..>": a path of two kernels per call -- the long-sequence backward -- counts the bytes of both)
+            c, missing = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, False
+            for part in full.split("+"):
+                short = part.split("<")[0]
+                cand = [k for k in summ if k == short] or [k for k in summ if short.startswith(k) or k.startswith(short)]
+                if not cand or "FETCH_SIZE" not in summ[cand[0]] or "WRITE_SIZE" not in summ[cand[0]]:
+                    print(f"{spec}: no FETCH_SIZE / WRITE_SIZE for {part} (sections: {sorted(summ)})", file=sys.stderr)
+                    missing = True
+                    break
+                c["FETCH_SIZE"] += summ[cand[0]]["FETCH_SIZE"]
+                c["WRITE_SIZE"] += summ[cand[0]]["WRITE_SIZE"]
+            if missing:
                 continue
-            c = summ[cand[0]]
             ent[side] = {"kernel": full, "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
                          "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
                          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, average per dispatch; bytes = (2 x FETCH_SIZE + "
