@@ -24,7 +24,7 @@ static int launch_bwd_fold_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   }
   // one persistent workgroup per CU (never more workgroups than problems: every workgroup reads its first problem's offsets)
   int grid = p.batch * p.heads;
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   if (grid > n_cu) grid = n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), smem, st, bp, tmax);
   return check_launch("hstu_attn_bwd(fold)");
@@ -43,7 +43,7 @@ static int launch_bwd_quad_inst(const HstuAttnBwdParams& bp, hipStream_t st) {
   if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
   int grid = p.batch * p.heads;
   if (QUAD_PERSIST) {
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const int n_cu = cu_count();
     if (grid > 2 * n_cu) grid = 2 * n_cu;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kQuadThreads), smem, st, bp, tmax);

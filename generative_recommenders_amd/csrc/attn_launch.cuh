@@ -106,7 +106,7 @@ static int launch_bwd_fold_bias_inst(const HstuAttnBwdParams& bp, hipStream_t st
   auto kern = hstu_attn_bwd_fold_bias_kernel<T, D>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   const int grid = p.batch < n_cu ? p.batch : n_cu;
   const int hw = 2 * p.max_seq_len + p.num_buckets;
   float* partial = (float*)bp.workspace;

@@ -8,7 +8,7 @@
 namespace hstu {
 
 static int solo_grid(int total, int per_cu) {
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   const int wgs = (total + kSoloWaves - 1) / kSoloWaves;
   return wgs < per_cu * n_cu ? wgs : per_cu * n_cu;      // as many workgroups as fit a CU (LDS) walk the problems
 }
@@ -35,7 +35,7 @@ template <typename T>
 static int launch_fwd_solo_bias(const HstuAttnParams& p, hipStream_t st) {
   const int tables = bias_table_bytes(p.max_seq_len, p.num_buckets);
   const int smem = kSoloWaves * (SoloCfg<T>::fwd_slice() + tables + kSoloBucketBytes);
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   auto kern = hstu_attn_fwd_solo_bias_kernel<T>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -59,7 +59,7 @@ static int launch_bwd_solo_bias(const HstuAttnBwdParams& bp, hipStream_t st) {
   auto kern = hstu_attn_bwd_solo_bias_kernel<T>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   const int grid = p.batch < n_cu ? p.batch : n_cu;
   const int hw = 2 * p.max_seq_len + p.num_buckets;
   float* partial = (float*)bp.workspace;

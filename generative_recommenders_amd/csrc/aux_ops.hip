@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __r
 }
 
 static int column_sum_groups(int64_t rows, int cols) {
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   const int col_blocks = (cols / 8 + 255) / 256;
   int64_t g = (int64_t)n_cu * 3 / col_blocks;       // 3 workgroups of 4 waves per CU, 8 rows of 16 bytes per lane in flight
   if (g > rows) g = rows;
@@ -257,7 +257,7 @@ int hstu_column_sum(const void* x, int64_t ldx, int64_t rows, int32_t cols, floa
 
 int hstu_calib_mfma_stream(int32_t iters, float* sink, double* flops, void* stream) {
   if (iters <= 0 || !sink) return set_error(HSTU_EINVAL, "hstu_calib_mfma_stream: iters > 0 and a sink are required");
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   const int blocks = n_cu * 2;          // 2 workgroups x 4 waves per CU: two waves per SIMD, as the product's MFMA kernels
   hipLaunchKernelGGL(calib_mfma_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
   if (flops) *flops = (double)blocks * 4 * (double)iters * 16 * (2.0 * 32 * 32 * 16);
@@ -266,7 +266,7 @@ int hstu_calib_mfma_stream(int32_t iters, float* sink, double* flops, void* stre
 
 int hstu_calib_read_stream(const void* src, size_t bytes, float* sink, void* stream) {
   if (!src || !sink || ((uintptr_t)src & 15)) return set_error(HSTU_EINVAL, "hstu_calib_read_stream: a 16-byte aligned source and a sink are required");
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   hipLaunchKernelGGL(calib_read_kernel, dim3(n_cu * 8), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (int64_t)(bytes / 16), sink);
   return check_launch("hstu_calib_read_stream");
 }

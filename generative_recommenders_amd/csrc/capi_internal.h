@@ -67,6 +67,19 @@ bool attn_bwd_fold_bias_lds(const HstuAttnParams& p, int base, int* ts_copies, i
 bool attn_bwd_fold_bias_applicable(const HstuAttnBwdParams& bp);
 int attn_bwd_bias_lds(const HstuAttnParams& p, int* ts_copies);
 
+// compute units of the CURRENT device (cached per device: a host may hold devices of different sizes)
+inline int cu_count() {
+  static int cache[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cache[dev] = n > 0 ? n : 256;
+  }
+  return cache[dev];
+}
 inline int pad_head_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 0)); }
 constexpr int kLdsBudget = 160 * 1024;
 // bytes of the bias tables a workgroup stages in LDS: pos_w (2N-1 floats), ts_w (nb+1 floats), N int64 timestamps,

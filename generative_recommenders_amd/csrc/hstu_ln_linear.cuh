@@ -543,7 +543,7 @@ static int launch_ln_linear(const LnLinearArgs& g, hipStream_t st) {
 #endif
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "ln_linear_fwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
-  static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = cu_count();
   const int grid = (int)(g.units < n_cu ? g.units : n_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kLnlThreads), smem, st, g);
   return check_launch("ln_linear_fwd");

@@ -596,8 +596,9 @@ def column_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: O
 
 
 def column_sum_supported(x: torch.Tensor) -> bool:
+    # (stride(0) >= columns: an expanded / broadcast gradient -- row stride 0 -- is torch's to sum)
     return bool(x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.stride(1) == 1 and
-                x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+                x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and x.stride(0) >= x.shape[1] and x.data_ptr() % 16 == 0)
 
 
 def calib_mfma_stream(device, iters: int = 4096):

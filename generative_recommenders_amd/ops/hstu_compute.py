@@ -71,7 +71,7 @@ class _LnUvqkFunction(torch.autograd.Function):
         # (``grad_on``: the caller's grad mode -- inside forward it is always off, and needs_input_grad ignores it)
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
         (nw, nb, w, beta), kmajor = _prepare_params((norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2,
-                                                    grad_on and any(ctx.needs_input_grad[1:5]))
+                                                    grad_on and any(ctx.needs_input_grad))
         uvqk, _, mean, rstd = _ln_uvqk(x, nw, nb, eps, w, kmajor, beta, want_normed=False)
         ctx.save_for_backward(x, nw, nb, mean, rstd, w)
         ctx.kmajor, ctx.eps = kmajor, eps
@@ -118,6 +118,7 @@ _UVQK_LINEAR = os.environ.get("HSTU_UVQK_LINEAR", "1") != "0"
 _KMAJOR_CACHE: dict = {}      # id(parameter) -> (weak reference, (version, dtype, data_ptr), copy); tensors compare element-wise,
                                # so they cannot key a (weak) dictionary themselves
 _PARAM_CACHE: dict = {}       # ids of a layer's parameters -> (weak references, key, casted copies): inference only
+_PARAM_CACHE_ON = os.environ.get("HSTU_PARAM_CACHE", "1") != "0"      # (inference-time cache of low-precision parameter copies)
 
 
 def invalidate_parameter_caches() -> None:
@@ -168,16 +169,20 @@ def _cast_fresh(params, dtype, kmajor_index):
 
 def _prepare_params(params, dtype, kmajor_index, tracked):
     """(copies, kmajor): a node's parameters in the activations' dtype, the UVQK weight (``kmajor_index``) as its K-contiguous
-    copy where hipBLASLt / the fused kernel want it.  ``tracked`` (the call records a graph: training): cast now, every
-    time -- a cache keyed on the version counter would miss writes through ``.data`` (legacy optimizers, EMA swaps) and
-    multiply by a stale weight silently; one launch per node covers all of them.  Otherwise the copies are cached per
-    parameter set until a version counter moves (invalidate_parameter_caches)."""
+    copy where hipBLASLt / the fused kernel want it.  ``tracked`` (the call records a graph -- ANY input wants a gradient, the
+    activations included: training, fine-tuning with frozen layers): cast now, every time -- a cache keyed on the version counter
+    would miss writes through ``.data`` (legacy optimizers, EMA swaps) and multiply by a stale weight silently; one launch per node
+    covers all of them.  Otherwise (inference) the copies are cached per parameter set until a version counter moves
+    (invalidate_parameter_caches; ``HSTU_PARAM_CACHE=0`` turns the cache off)."""
     want_kmajor = kmajor_index is not None and _UVQK_LINEAR and params[kmajor_index].is_cuda
     kidx = kmajor_index if want_kmajor else None
-    if tracked:
+    if tracked or not _PARAM_CACHE_ON:
         return _cast_fresh(params, dtype, kidx), want_kmajor
     ids = tuple(id(t) for t in params)
-    key = tuple((t._version, t.data_ptr(), t.dtype) for t in params) + (dtype, want_kmajor)
+    try:
+        key = tuple((t._version, t.data_ptr(), t.dtype) for t in params) + (dtype, want_kmajor)
+    except RuntimeError:        # (a parameter created under torch.inference_mode has no version counter)
+        return _cast_fresh(params, dtype, kidx), want_kmajor
     hit = _PARAM_CACHE.get(ids)
     if hit is not None and hit[1] == key and all(r() is t for r, t in zip(hit[0], params)):
         return hit[2], want_kmajor
@@ -292,7 +297,7 @@ class _ComputeOutputFunction(torch.autograd.Function):
         # recompute of y regenerate it from the seed
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, output_weight.dtype)
         (norm_weight, norm_bias, output_weight), _ = _prepare_params((norm_weight, norm_bias, output_weight), x.dtype, None,
-                                                                      grad_on and any(ctx.needs_input_grad[3:6]))
+                                                                      grad_on and any(ctx.needs_input_grad))
         y, mean, rstd = _launch.norm_mul_fwd(attn, u, norm_weight, norm_bias, eps, num_heads, linear_dim, group_norm,
                                              concat_ux, dropout_ratio, seed)
         out = torch.addmm(x, y, output_weight)
@@ -358,7 +363,7 @@ class _PreprocessAndAttentionFunction(torch.autograd.Function):
                 recompute_uvqk, recompute_normed_x, user_order=None, grad_on=True):
         ctx.param_dtypes = (norm_weight.dtype, norm_bias.dtype, uvqk_weight.dtype, uvqk_bias.dtype)
         (norm_weight, norm_bias, uvqk_weight, uvqk_bias), ctx.kmajor = _prepare_params(
-            (norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2, grad_on and any(ctx.needs_input_grad[1:5]))
+            (norm_weight, norm_bias, uvqk_weight, uvqk_bias), x.dtype, 2, grad_on and any(ctx.needs_input_grad))
         uvqk, normed_x, mean, rstd = _ln_uvqk(x, norm_weight, norm_bias, norm_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
                                               want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads
@@ -441,7 +446,7 @@ class _STULayerFunction(torch.autograd.Function):
         ctx.param_dtypes = tuple(t.dtype for t in (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight))
         (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight), ctx.kmajor = _prepare_params(
             (in_nw, in_nb, uvqk_weight, uvqk_bias, out_nw, out_nb, output_weight), x.dtype, 2,
-            grad_on and any(ctx.needs_input_grad[1:8]))
+            grad_on and any(ctx.needs_input_grad))
         uvqk, normed_x, mean, rstd = _ln_uvqk(x, in_nw, in_nb, in_eps, uvqk_weight, ctx.kmajor, uvqk_bias,
                                               want_normed=not recompute_normed_x)
         hv, ha = hidden_dim * num_heads, attn_dim * num_heads

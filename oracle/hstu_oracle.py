@@ -571,7 +571,7 @@ def dropout_keep_mask(seed: int, rows: int, out_stride: int, dropout_ratio: floa
     survivors are scaled by 1 / (1 - p); the backward reuses the mask) and, bit for bit, the counter-based generator of
     the HIP kernels (csrc/norm_kernels.inc, drop_hash) -- the reference's own Philox stream (tl.rand / F.dropout) is not
     reproducible across implementations, so parity under dropout is (a) this exact mask and (b) the statistics.
-    Element e = row * out_stride + col; pair j = e >> 1 shares one 32-bit hash (murmur3's fmix32 of the pair index xor a key), element e takes its low (e even) or
+    Element e = row * out_stride + col; pair j = e >> 1 shares one 32-bit hash (murmur3's fmix32 of the pair index xor a key, the seed's high word added behind the first multiply), element e takes its low (e even) or
     high (e odd) 16 bits; keep iff r16 >= thr, thr = clamp(round(p * 65536), 1, 65535); scale = 65536 / (65536 - thr).
     """
     thr = int(min(max(np.floor(float(np.float32(dropout_ratio)) * 65536.0 + 0.5), 1.0), 65535.0)) if dropout_ratio > 0 else 0
@@ -589,7 +589,8 @@ def dropout_keep_mask(seed: int, rows: int, out_stride: int, dropout_ratio: floa
     k = (s1 + mul(hi, 0x9E3779B9)) & M
     key = s0 ^ (((k << np.uint64(16)) | (k >> np.uint64(16))) & M)          # both seed words and the index's high word
     h = lo ^ key
-    h ^= h >> np.uint64(16); h = mul(h, 0x85EBCA6B); h ^= h >> np.uint64(13); h = mul(h, 0xC2B2AE35); h ^= h >> np.uint64(16)
+    # (both seed words once more behind the first multiply: without it the masks of two seeds are index-XOR permutations of each other)
+    h ^= h >> np.uint64(16); h = mul(h, 0x85EBCA6B); h = (h + (s1 ^ (((s0 << np.uint64(13)) | (s0 >> np.uint64(19))) & M))) & M; h ^= h >> np.uint64(13); h = mul(h, 0xC2B2AE35); h ^= h >> np.uint64(16)
     r16 = np.where((e & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
     keep = (r16 >= np.uint64(thr)).reshape(rows, out_stride)
     return keep, 65536.0 / (65536.0 - thr)

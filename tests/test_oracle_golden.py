@@ -347,3 +347,29 @@ def test_dropout_generator_statistics():
     # an element index beyond 2^33: the pair index's high word enters the key (no repetition of the first 2^33 elements' mask)
     a = O.dropout_keep_mask(7, 1, 4096, 0.5)[0]
     assert a.shape == (1, 4096) and 0.4 < a.mean() < 0.6
+
+
+def test_dropout_masks_of_two_seeds_are_not_index_permutations_of_each_other():
+    """Round 5's advisor: with the seed only XORed into the pair index, mask_B[i] == mask_A[i ^ d] for EVERY pair of seeds (d = the
+    XOR of their keys), and seeds with equal keys gave identical masks.  The generator now adds both seed words behind its first
+    multiply: for seed pairs that differ in the low word, the high word, or both, no XOR shift of the pair index maps one mask onto
+    the other -- the agreement under the old relation's d (and under every d of a scan) is what independent masks give."""
+    rows, stride, p = 64, 2048, 0.5
+    n_pairs = rows * stride // 2
+
+    def pair_bits(seed):
+        keep = O.dropout_keep_mask(seed, rows, stride, p)[0].reshape(-1)
+        return keep[0::2].astype(np.int8) * 2 + keep[1::2].astype(np.int8)       # both uniforms of a pair index
+
+    def old_key(seed):
+        s0, s1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+        return s0 ^ (((s1 << 16) | (s1 >> 16)) & 0xFFFFFFFF)
+
+    idx = np.arange(n_pairs)
+    for a, b in ((42, 43), (42, 42 ^ (1 << 32)), (7, 7 ^ 0x10000), (2 ** 40 + 7, 2 ** 41 + 9), (5, 5 ^ (0x8000 << 32) ^ 0x8000)):
+        ma, mb = pair_bits(a), pair_bits(b)
+        assert not np.array_equal(ma, mb), (a, b)
+        d = (old_key(a) ^ old_key(b)) & (n_pairs - 1)
+        for shift in {d, 1, 2, 0x10, 0x100} | set(range(0, n_pairs, n_pairs // 64)):
+            agree = float((mb == ma[idx ^ shift]).mean())
+            assert agree < 0.30, (a, b, shift, agree)      # independent pairs of fair bits agree in 1/4 of the places

@@ -122,14 +122,14 @@ def lint(path, kernel_pat):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("files", nargs="*")
-    ap.add_argument("--kernel", default="hstu_attn_bwd_wide")
+    ap.add_argument("--kernel", default="hstu_attn_bwd_fold")
     ap.add_argument("--flags", default="")
     a = ap.parse_args()
     files = list(a.files)
     tmp = None
     if not files:
         tmp = tempfile.mkdtemp()
-        for tu in ("attn_wide_bf16", "attn_wide_f16"):
+        for tu in ("attn_fold_bf16", "attn_long_bf16"):      # (live translation units; --kernel hstu_attn_bwd_dkv for the second)
             out = os.path.join(tmp, tu + ".s")
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I.", "-I../../include", "--cuda-device-only", "-S",
                    tu + ".hip", "-o", out] + a.flags.split()
