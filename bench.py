@@ -696,10 +696,13 @@ def projection_section(rows, D, device):
         "uvqk_fwd": (lambda: _uvqk_gemm(x, w_mul, kmajor, b_uvqk), 2.0 * rows * D * 4 * D),
         "uvqk_dgrad": (lambda: _uvqk_dgrad(g_uvqk, w_mul, kmajor), 2.0 * rows * D * 4 * D),
         "uvqk_wgrad": (lambda: weight_grad_mm(x, g_uvqk), 2.0 * rows * D * 4 * D),
-        "out_fwd": (lambda: torch.addmm(x, y3, w_out), 2.0 * rows * 3 * D * D),      # + the residual
+        "out_fwd": (lambda: torch.addmm(x, y3, w_out), 2.0 * rows * 3 * D * D),      # + the residual: copy of x + in-place GEMM
         "out_dgrad": (lambda: torch.mm(g_out, w_out.t()), 2.0 * rows * 3 * D * D),
         "out_wgrad": (lambda: weight_grad_mm(y3, g_out), 2.0 * rows * 3 * D * D),
     })
+    lt_ok = _launch.addmm_residual_supported(x, y3, w_out)
+    if lt_ok:
+        cases["out_fwd_one_launch"] = (lambda: _launch.addmm_residual(x, y3, w_out), 2.0 * rows * 3 * D * D)
     k512_ok = _launch.linear_k512_supported(g_out, 3 * D)
     if k512_ok:
         cases["out_dgrad_k512"] = (lambda: _launch.linear_k512(g_out, w_out), 2.0 * rows * 3 * D * D)
@@ -725,6 +728,10 @@ def projection_section(rows, D, device):
             res[name].update(algorithmic_GBps=round(gbps, 0), hbm_frac=round(gbps / HBM_PEAK_GBPS, 3))
         if name.startswith("uvqk_fwd_fused"):
             res[name]["kernel"] = "hstu_ln_linear_fwd_kernel (LayerNorm inside; what the product runs)"
+        if name == "out_fwd_one_launch":
+            res[name]["kernel"] = "hipBLASLt matmul with separate C and D (hstu_addmm_residual; what the product runs)"
+        if name == "out_fwd":
+            res[name]["kernel"] = "torch.addmm: copy of x + hipBLASLt in place (comparator: the product runs out_fwd_one_launch)" if lt_ok else "torch.addmm"
         if name == "out_dgrad_k512":
             res[name]["kernel"] = "hstu_ln_linear_fwd_kernel without the LayerNorm (hstu_linear_k512; what the product runs)"
         if name == "out_dgrad":

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime ou
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HSTU_HIP_LIBRARY overrides the in-tree build (A/B measurements of kernel variants, packaged installs)
 LIB_PATH = os.environ.get("HSTU_HIP_LIBRARY") or os.path.join(_HERE, "libhstu_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 HSTU_DTYPE_BF16, HSTU_DTYPE_F16, HSTU_DTYPE_F32 = 0, 1, 2
 HSTU_INDEX_I32, HSTU_INDEX_I64 = 0, 1
@@ -92,6 +92,8 @@ SIGNATURES = {
     "hstu_ln_linear_fwd": (_int, [_vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp]),
     "hstu_linear_k512_supported": (_int, [_i64, _i32, _i32, _int]),
     "hstu_linear_k512": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp]),
+    "hstu_addmm_residual_supported": (_int, []),
+    "hstu_addmm_residual": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _int, _vp, C.c_size_t, _vp]),
     "hstu_layer_norm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _int, _vp]),
     "hstu_swish_layer_norm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _int, _vp]),
     "hstu_swish_layer_norm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _int, _vp]),

@@ -453,6 +453,37 @@ def linear_k512(x, w_nk, bias=None):
     return y
 
 
+_ADDMM_LT = os.environ.get("HSTU_ADDMM_LT", "1") != "0"      # 0: torch.addmm (copy + in-place GEMM), the comparator
+_ADDMM_WS: dict = {}          # device -> hipBLASLt workspace (32 MiB, as PyTorch's own), allocated once
+
+
+def addmm_residual_supported(c, a, b) -> bool:
+    """whether ``c + a @ b`` can run as ONE hipBLASLt launch with separate C and D buffers (hstu_addmm_residual): 2-D 16-bit CUDA
+    operands of one dtype, c of the result's shape, rows contiguous and 16-byte aligned"""
+    if not (_ADDMM_LT and a.is_cuda and a.dim() == 2 and b.dim() == 2 and c.dim() == 2 and a.dtype in (torch.bfloat16, torch.float16)
+            and b.dtype == a.dtype and c.dtype == a.dtype and c.shape == (a.shape[0], b.shape[1]) and a.shape[1] == b.shape[0]):
+        return False
+    for t in (a, b, c):
+        if t.stride(1) != 1 or t.stride(0) < t.shape[1] or t.stride(0) % 8 or t.data_ptr() % 16:
+            return False
+    return a.shape[0] > 0 and bool(L.lib().hstu_addmm_residual_supported())
+
+
+def addmm_residual(c, a, b):
+    """``c + a @ b`` (fp32 accumulation) without the copy of c that torch.addmm makes: hipBLASLt reads c and writes the result"""
+    L.require_gpu_tensor(a, "a")
+    m, k = a.shape
+    n = b.shape[1]
+    d = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    ws = _ADDMM_WS.get(a.device)
+    if ws is None:
+        ws = _ADDMM_WS[a.device] = torch.empty(32 << 20, dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        L.check(L.lib().hstu_addmm_residual(c.data_ptr(), c.stride(0), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), d.data_ptr(), n,
+                                            m, n, k, L.torch_dtype_code(a.dtype), ws.data_ptr(), ws.numel(), L.current_stream_ptr(a.device)))
+    return d
+
+
 def layer_norm_bwd(dy, x, weight, mean, rstd, dresidual=None):
     """``dresidual``: a gradient that reaches x around the norm; added inside the kernel (dx = LN'(dy) + dresidual)."""
     dy, x = dy.contiguous(), x.contiguous()

@@ -285,6 +285,14 @@ def _out_dgrad(dout, Wo):
     return torch.mm(dout, Wo.t())
 
 
+def _residual_addmm(x, y, w):
+    """out = x + y @ w: ONE hipBLASLt launch that reads x and writes out (hstu_addmm_residual, ABI v13) where the operands allow it,
+    else torch.addmm -- the same library behind a copy of x into the result and an in-place GEMM"""
+    if _launch.addmm_residual_supported(x, y, w):
+        return _launch.addmm_residual(x, y, w)
+    return torch.addmm(x, y, w)
+
+
 class _ComputeOutputFunction(torch.autograd.Function):
     """out = x + [u, attn, u*Norm(attn)] @ W_o as ONE node (HSTUComputeOutputFunction,
     triton_hstu_linear.py:1137-1308): y is recomputed in backward unless asked otherwise."""
@@ -300,7 +308,7 @@ class _ComputeOutputFunction(torch.autograd.Function):
                                                                       grad_on and any(ctx.needs_input_grad))
         y, mean, rstd = _launch.norm_mul_fwd(attn, u, norm_weight, norm_bias, eps, num_heads, linear_dim, group_norm,
                                              concat_ux, dropout_ratio, seed)
-        out = torch.addmm(x, y, output_weight)
+        out = _residual_addmm(x, y, output_weight)
         saved = [attn, u, norm_weight, norm_bias, mean, rstd, output_weight]
         if not recompute_y:
             saved.append(y)
@@ -457,7 +465,7 @@ class _STULayerFunction(torch.autograd.Function):
                                 max_attn_len, contextual_seq_len, 0, user_order=user_order).view(-1, hv)
         y, omean, orstd = _launch.norm_mul_fwd(attn, uvqk[:, :hv], out_nw, out_nb, out_eps, num_heads, hidden_dim, group_norm,
                                                concat_ux, dropout_ratio, seed, u_is_preactivation=True)
-        out = torch.addmm(x, y, output_weight)
+        out = _residual_addmm(x, y, output_weight)
         saved = [x, in_nw, in_nb, mean, rstd, uvqk_weight, uvqk_bias, seq_offsets, attn, out_nw, out_nb, omean, orstd,
                  output_weight]
         ctx.has_targets = num_targets is not None

@@ -7,11 +7,17 @@ from typing import Optional
 import torch
 
 from generative_recommenders_amd.common import HammerKernel
+from generative_recommenders_amd.ops import _launch
 
 
 def addmm(input: torch.Tensor, mat1: torch.Tensor, mat2: torch.Tensor,
           kernel: HammerKernel = HammerKernel.HIP) -> torch.Tensor:
     del kernel
+    # (a 2-D ``input`` of the result's shape -- the STU layer's residual -- without ATen's copy of it into the result; gradients
+    # need the autograd-aware torch op)
+    if not (torch.is_grad_enabled() and (input.requires_grad or mat1.requires_grad or mat2.requires_grad)) and \
+            _launch.addmm_residual_supported(input, mat1, mat2):
+        return _launch.addmm_residual(input, mat1, mat2)
     return torch.addmm(input, mat1, mat2)
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSTU_ABI_VERSION 12
+#define HSTU_ABI_VERSION 13
 
 enum {
   HSTU_OK = 0,
@@ -251,6 +251,16 @@ int hstu_swish_layer_norm_bwd(const void* dy, const void* x, const void* weight,
 int hstu_linear_k512_supported(int64_t rows, int32_t k, int32_t n, int dtype);
 int hstu_linear_k512(const void* x, int64_t ldx, const void* w_nk, const void* bias, void* y, int64_t ldy,
                      int64_t rows, int32_t k, int32_t n, int dtype, void* stream);
+/* ABI v13: d = a . b + c, row-major, fp32 accumulation, C and D DIFFERENT buffers -- the output stage out = x + y . W_o
+ * (`torch.addmm(x, y, output_weight)`, ops/hstu_compute.py:92-136; the reference's own kernel for it: ops/triton/triton_addmm.py:185-340)
+ * as ONE hipBLASLt launch.  Through torch.addmm the same product is a copy of x into the result followed by an in-place GEMM with
+ * beta = 1 (40 us per layer at 204,800 x 512).  A plain library GEMM: hipBLASLt is looked up at run time (dlopen), nothing links
+ * against it; _supported() says whether it was found (else the caller keeps torch.addmm -- the same library behind it).
+ * a (m, k) lda, b (k, n) ldb, c (m, n) ldc, d (m, n) ldd: leading dimensions in elements, operands 16-byte aligned, bf16 / fp16;
+ * workspace: any size (0 / NULL allowed), handed to hipBLASLt's heuristic as the upper bound. */
+int hstu_addmm_residual_supported(void);
+int hstu_addmm_residual(const void* c, int64_t ldc, const void* a, int64_t lda, const void* b, int64_t ldb, void* d, int64_t ldd,
+                        int64_t m, int32_t n, int32_t k, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int hstu_layer_norm_bwd(const void* dy, const void* x, const void* weight,
                         const float* mean, const float* rstd, void* dx,
                         float* dweight, float* dbias, float* partial_ws,

@@ -45,7 +45,7 @@ def test_ctypes_signature_table_covers_header():
 
 def test_abi_version_and_error_string(lib):
     from generative_recommenders_amd import _lib as L
-    assert lib.hstu_abi_version() == L.ABI_VERSION == 12
+    assert lib.hstu_abi_version() == L.ABI_VERSION == 13
     assert isinstance(lib.hstu_last_error(), bytes)
 
 

@@ -144,3 +144,49 @@ def test_bias_gradient_of_the_layer_is_the_column_sum_of_d_uvqk():
     want = d.double().sum(dim=0)
     got = _launch.column_sum(d).double()
     assert float((got - want).abs().max()) <= 2e-6 * float(d.double().abs().sum(dim=0).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(4096, 1536, 512), (1000, 512, 2048), (37, 64, 40), (1, 1536, 512)])
+def test_addmm_residual_one_launch_matches_fp64_and_torch(shape, dtype):
+    """hstu_addmm_residual (ABI v13): out = x + y @ w as ONE hipBLASLt launch with separate C and D buffers (torch.addmm copies x into
+    the result first) -- against the fp64 product, against torch.addmm, x untouched, strided x and y (views of wider buffers)."""
+    from generative_recommenders_amd.ops import _launch
+
+    m, k, n = shape
+    g = torch.Generator(device="cpu").manual_seed(m + k + n)
+    xw = torch.randn(m, n + 8, generator=g).to(dtype).cuda()
+    yw = torch.randn(m, k + 16, generator=g).to(dtype).cuda()
+    w = (torch.randn(k, n, generator=g) / k ** 0.5).to(dtype).cuda()
+    x, y = xw[:, :n], yw[:, 8:8 + k]                 # row strides n + 8 / k + 16, 16-byte aligned starts
+    assert _launch.addmm_residual_supported(x, y, w), "hipBLASLt must be loadable on the GPU box"
+    x0 = x.clone()
+    out = _launch.addmm_residual(x, y, w)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x0) and out.shape == (m, n) and out.dtype == dtype and out.is_contiguous()
+    ref = x.double() + y.double() @ w.double()
+    rel = float((out.double() - ref).norm() / ref.norm())
+    assert rel < (3e-3 if dtype == torch.bfloat16 else 4e-4), rel            # the rounding of one 16-bit result
+    tor = torch.addmm(x, y, w)
+    assert float((out.float() - tor.float()).abs().max()) <= float(ref.abs().max()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10)
+    # a second call reuses the planned problem; another shape in between does not disturb it
+    _launch.addmm_residual(x[: max(1, m // 2)], y[: max(1, m // 2)], w)
+    assert torch.equal(_launch.addmm_residual(x, y, w), out)
+
+
+def test_addmm_op_takes_the_one_launch_path_only_without_autograd():
+    from generative_recommenders_amd.ops.mm import addmm
+
+    x = torch.randn(256, 512, device="cuda", dtype=torch.bfloat16)
+    y = torch.randn(256, 1536, device="cuda", dtype=torch.bfloat16)
+    w = torch.randn(1536, 512, device="cuda", dtype=torch.bfloat16) / 39.0
+    with torch.no_grad():
+        a = addmm(x, y, w)
+    wr = w.clone().requires_grad_()
+    b = addmm(x, y, wr)                      # autograd: torch's op
+    assert b.requires_grad and float((a.float() - b.float()).abs().max()) <= 2 ** -7 * float(b.float().abs().max())
+    b.float().sum().backward()
+    assert wr.grad is not None
+    bias = torch.randn(512, device="cuda", dtype=torch.bfloat16)     # 1-D input (a bias): torch's op
+    with torch.no_grad():
+        assert addmm(bias, y, w).shape == (256, 512)
