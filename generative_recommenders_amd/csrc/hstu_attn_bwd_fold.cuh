@@ -127,7 +127,12 @@ HSTU_DEV void fold_pair_x(const HstuAttnParams& p, const MaskCtx& mc, const char
   // clamped copy of a real row (LDS-DMA cannot zero-fill), so only tiles entirely inside the sequence need no mask.
   Frag pb[2], dsb[2];
   int mode;   // wave-uniform: 0 = no mask needed, 1 = plain causal, 2 = general mask algebra
-  if (mc.simple) mode = (k0 < i0 && i0 + 32 <= len) ? 0 : 1;    // strictly below the diagonal and all rows real
+  // Target rows only (no window, no contextual rows: what DLRM-v3 runs, modules/dlrm_hstu.py:207-214): a query tile whose rows all lie
+  // in front of the first target sees plain causal masks -- its keys are <= its rows -- and takes the plain path (two compares and the
+  // lane-constant patterns instead of the general tile predicate's ~100 scalar instructions and 16 x 8 vector instructions of mask
+  // bits); of a 7-tile user with <= 20 targets that is every pair but the last one or two query tiles'.
+  const bool plain = mc.simple || (HSTU_TARGETS_PLAIN && mc.has_targets && mc.win == 0 && mc.ctx == 0 && i0 + 32 <= min(len, mc.max_id));
+  if (plain) mode = (k0 < i0 && i0 + 32 <= len) ? 0 : 1;    // strictly below the diagonal and all rows real
   else mode = (i0 + 32 <= len && mc.pair_fully_valid(i0, 32, k0, 32)) ? 0 : 2;
   const int key_id = mc.id_of(key);
   const int key_bits = key_ok ? -1 : 0;

@@ -352,7 +352,11 @@ __global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void
   // plain causal, rows aligned with the key tiles (no delta_q shift, no sliding-window start), |alpha| in the range where
   // alpha * 1e30 neither overflows nor loses the mask: the diagonal tile's mask is a lane constant (mode 4 below)
   const float aabs = fabsf(p.alpha);
-  const bool diag_fast = !BIAS && mc.simple && i_shift == 0 && kv_lo == 0 && aabs > 1e-20f && aabs < 1e6f;
+  // (target rows only -- no window, no contextual rows, no delta: DLRM-v3's call -- and every row of this wave in front of the first
+  // target: the wave's masks are the plain causal ones, it takes the plain path's two compares per tile instead of the general
+  // predicates' ~100 scalar instructions, and its diagonal tile the lane-constant pattern)
+  const bool wave_plain = mc.simple || (HSTU_TARGETS_PLAIN && mc.has_targets && mc.win == 0 && mc.ctx == 0 && i_shift == 0 && r0 + 32 <= min(len, mc.max_id));
+  const bool diag_fast = !BIAS && wave_plain && i_shift == 0 && kv_lo == 0 && aabs > 1e-20f && aabs < 1e6f;
 
   // ---- K/V tiles stream through an NS-deep LDS ring filled by LDS-DMA: tiles t+1 .. t+NS-1 are in
   // flight while tile t is computed; one raw barrier per tile, loads are never drained in the loop
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void
     // batches -- no targets, window or contextual rows -- take two compares instead)
     const int i0w = r0 + i_shift;
     bool tile_act, tile_full;
-    if (mc.simple) {
+    if (wave_plain) {
       tile_act = i0w < len && j0 <= min(i0w + 31, len - 1);
       tile_full = j0 + 32 <= i0w;     // strictly below this wave's first row (then also j0 + 32 <= len)
     } else {
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(kFwdThreads, PRECISE ? 2 : HSTU_FWD_MIN_WAVES) void
       // the sigmoid exactly 0 and P' = x * 0 = -0 -- the element-wise block needs no mask code; the predicate, key
       // (r&3) + 8 (r>>2) + 4 hf <= query n32, is a compare against a lane constant).  Every other tile such a wave visits lies
       // strictly below its rows: no mask at all (rows past the sequence end are zero-filled: silu(0) = 0).
-      const int mode = tile_full ? 0 : (mc.simple ? (diag_fast ? 4 : 1) : (mc.ctx == 0 ? 3 : 2));
+      const int mode = tile_full ? 0 : (wave_plain ? (diag_fast ? 4 : 1) : (mc.ctx == 0 ? 3 : 2));
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;

@@ -269,6 +269,9 @@ struct MaskCtx {
   }
 };
 
+#ifndef HSTU_TARGETS_PLAIN
+#define HSTU_TARGETS_PLAIN 1   // 0: query tiles in front of the first target take the general mask path too (the comparator of tools/ab_bwd.py --targets)
+#endif
 // SCALAR: the user index is wave-uniform and num_targets read-only -> sload_index
 template <bool SCALAR = false>
 HSTU_DEV MaskCtx make_mask_ctx(const HstuAttnParams& p, int b, int len) {

@@ -10,6 +10,8 @@ Differences, all by construction of this package (single backend, no dispatch):
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -23,6 +25,9 @@ def _pad_head_dim(t: torch.Tensor) -> torch.Tensor:
     mult = 16 // t.element_size()
     pad = (-t.shape[-1]) % mult
     return F.pad(t, (0, pad)) if pad else t
+
+
+_PRECISE = os.environ.get("HSTU_ATTN_PRECISE") == "1"      # read once, as the library does (csrc/attn_misc.hip, attn_fwd_precise_enabled)
 
 
 class _HstuMhaFunction(torch.autograd.Function):
@@ -47,6 +52,15 @@ class _HstuMhaFunction(torch.autograd.Function):
         q, k, v, seq_offsets = ctx.saved_tensors[:4]
         num_targets = ctx.saved_tensors[4] if ctx.has_targets else None
         max_seq_len, alpha, max_attn_len, contextual_seq_len, min_full = ctx.args
+        if _PRECISE and q.dtype in (torch.bfloat16, torch.float16):
+            # HSTU_ATTN_PRECISE=1, backward: the 16-bit kernels round P' and dS' to the I/O dtype in front of their second MFMAs (one
+            # rounding of the size of the output's own; the folded kernel has no registers for a second fragment pair: 256 of 256).
+            # The precise backward is the fp32 instantiation of the same kernels on the same (exactly representable) inputs, its
+            # gradients rounded ONCE to the I/O dtype: error = the output rounding alone.  Several times the time and four fp32 copies;
+            # a numerical mode, not the measured path.
+            dq, dk, dv = _launch.attn_bwd(dout.float(), q.float(), k.float(), v.float(), seq_offsets, num_targets, max_seq_len, alpha,
+                                          1.0 / max_seq_len, max_attn_len, contextual_seq_len, min_full, user_order=ctx.user_order)
+            return None, None, dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None, None, None, None, None
         dq, dk, dv = _launch.attn_bwd(dout, q, k, v, seq_offsets, num_targets, max_seq_len, alpha,
                                       1.0 / max_seq_len, max_attn_len, contextual_seq_len, min_full, user_order=ctx.user_order)
         return None, None, dq, dk, dv, None, None, None, None, None, None

@@ -1,7 +1,8 @@
 """HSTU_ATTN_PRECISE=1 (csrc/hstu_attn_fwd.cuh, PRECISE): the forward feeds P' to the second MFMA as value + rounding remainder, so
 the only rounding left in `out` is the one of the output itself.  Measured here against the fp64 oracle ROUNDED to the I/O dtype
 (north_star's 1e-3 is below what a bf16 output can hold: rounding alone is 1.66e-3 relative Frobenius): the default kernel sits
-at ~1.66e-3 above that floor-reference, the precise one at a fraction of it.  The switch is read once per process: child runs."""
+at ~1.66e-3 above that floor-reference, the precise one at a fraction of it.  The backward's precise mode is the fp32 instantiation of
+the kernels on the same inputs with the gradients rounded once (ops/hstu_attention.py).  The switch is read once per process: child runs."""
 import json
 import os
 import subprocess
@@ -26,13 +27,23 @@ for dt, d in ((torch.bfloat16, 128), (torch.bfloat16, 64), (torch.float16, 128))
     lengths = np.array([200, 187, 200, 129, 64, 200]); off = O.complete_cumsum(lengths.astype(np.int64)); L = int(off[-1])
     mk = lambda: torch.from_numpy(rng.standard_normal((L, H, d)) * 0.5).to(dt)
     q, k, v = mk(), mk(), mk()
-    got = hstu_mha(N, d ** -0.5, q.cuda(), k.cuda(), v.cuda(), torch.from_numpy(off).cuda()).float().cpu().double().numpy()
+    do = torch.from_numpy(rng.standard_normal((L, H, d))).to(dt)
+    qd, kd, vd = (t.cuda().requires_grad_() for t in (q, k, v))
+    o = hstu_mha(N, d ** -0.5, qd, kd, vd, torch.from_numpy(off).cuda())
+    o.backward(do.cuda())
+    got = o.detach().float().cpu().double().numpy()
     ref = O.hstu_mha_fwd(N, d ** -0.5, q.double().numpy(), k.double().numpy(), v.double().numpy(), off)
     ref_r = torch.from_numpy(ref).to(dt).double().numpy()
     key = f"{str(dt)[6:]}_{d}"
     out[key] = dict(kernel=_launch.attn_fwd_kernel_name(dt, d, d, N, heads=H),
                     rel_fro=float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
                     rel_fro_vs_rounded_ref=float(np.linalg.norm(got - ref_r) / np.linalg.norm(ref)))
+    refs = O.hstu_mha_bwd(N, d ** -0.5, do.double().numpy(), q.double().numpy(), k.double().numpy(), v.double().numpy(), off)
+    for nm, g, r in zip(("dq", "dk", "dv"), (qd.grad, kd.grad, vd.grad), refs):
+        g = g.float().cpu().double().numpy()
+        r_r = torch.from_numpy(r).to(dt).double().numpy()
+        out[key][nm] = dict(rel_fro=float(np.linalg.norm(g - r) / np.linalg.norm(r)),
+                            rel_fro_vs_rounded_ref=float(np.linalg.norm(g - r_r) / np.linalg.norm(r)))
 print("RESULT " + json.dumps(out))
 """ % ROOT
 
@@ -57,3 +68,9 @@ def test_precise_forward_reaches_the_output_rounding_floor():
         assert prec[key]["rel_fro_vs_rounded_ref"] <= 0.5 * floor, (key, prec[key])
         assert prec[key]["rel_fro_vs_rounded_ref"] < 0.5 * base[key]["rel_fro_vs_rounded_ref"], (key, base[key], prec[key])
         assert prec[key]["rel_fro"] <= 1.1 * floor, (key, prec[key])     # total error = the output's own rounding
+        # the backward's precise mode (ops/hstu_attention.py: the fp32 instantiations on the same inputs, gradients rounded once):
+        # against the rounded reference only the elements whose rounding flips are left
+        for nm in ("dq", "dk", "dv"):
+            assert prec[key][nm]["rel_fro_vs_rounded_ref"] <= 0.1 * floor, (key, nm, prec[key][nm])
+            assert prec[key][nm]["rel_fro"] <= 1.1 * floor, (key, nm, prec[key][nm])
+            assert base[key][nm]["rel_fro_vs_rounded_ref"] > 0.5 * floor, (key, nm, base[key][nm])       # (the default kernels: one rounding more)

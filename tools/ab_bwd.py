@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--launches", type=int, default=10)
     ap.add_argument("--fwd", action="store_true")
+    ap.add_argument("--targets", action="store_true", help="num_targets = randint(1, 21) per user (the M-targets workload of bench.py)")
     a = ap.parse_args()
     dev = "cuda"
     H, d, B, N = a.heads, a.head_dim, a.users, a.max_seq_len
@@ -51,7 +52,8 @@ def main():
     dfused = torch.zeros_like(fused)
     dq, dk, dv = torch.split(dfused, [d, d, d], dim=-1)
     bp = L.HstuAttnBwdParams()
-    _launch._fill_attn_params(bp.fwd, q, k, v, None, off, None, N, d ** -0.5, 1.0 / N, 0, 0, 0, 0)
+    nt = torch.randint(1, 21, (B,), generator=gen, device=dev, dtype=torch.int64) if a.targets else None
+    _launch._fill_attn_params(bp.fwd, q, k, v, None, off, nt, N, d ** -0.5, 1.0 / N, 0, 0, 0, 0)
     bp.fwd.out = out.data_ptr()
     bp.fwd.o_row_stride, bp.fwd.o_head_stride = out.stride(0), out.stride(1)
     bp.dout, bp.dq, bp.dk, bp.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
