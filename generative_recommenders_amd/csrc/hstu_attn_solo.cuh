@@ -23,39 +23,40 @@ struct SoloCfg {
   static constexpr int TILE = 32 * kSoloD * Elem<T>::kBytes;      // 2048
   static constexpr int UPR = kSoloD * Elem<T>::kBytes / 16;        // 4
   // per wave: K, V, Q (2 tiles each; forward: 12 KiB -> 3 workgroups per CU) + dO and 2 dS' tiles (backward: 20 KiB)
-  static constexpr int bwd_slice() { return 8 * TILE + 2 * 32 * 64; }
-  static constexpr int fwd_slice() { return 6 * TILE; }   // the output tile is parked over the query tile it came from
+  static constexpr int bwd_slice(int tpt = 2) { return tpt * (4 * TILE + 32 * 64); }
+  static constexpr int fwd_slice(int tpt = 2) { return 3 * tpt * TILE; }   // the output tile is parked over the query tile it came from
 };
 
 // [rows of one tensor] -> this wave's LDS tiles, zero filled: 2 units (16 B) per lane and tile.  Two halves: the
 // loads (issue) and the LDS writes (commit), so that all the loads of a problem are in flight before the first write.
-template <typename T>
-HSTU_DEV void solo_issue(u32x4 (&reg)[4], const char* base, int64_t row_stride_bytes, int len, int real_d, int nt, int lane) {
+template <typename T, int TPT = 2>
+HSTU_DEV void solo_issue(u32x4 (&reg)[2 * TPT], const char* base, int64_t row_stride_bytes, int len, int real_d, int nt, int lane) {
   using S = SoloCfg<T>;
   constexpr int EPU = 16 / Elem<T>::kBytes;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {                   // j = 2 * tile + half
+  for (int j = 0; j < 2 * TPT; ++j) {             // j = 2 * tile + half
     const int u = (j & 1) * 64 + lane, row = 32 * (j >> 1) + u / S::UPR, unit = u % S::UPR;
     const bool ok = (j >> 1) < nt && row < len && unit * EPU < real_d;
     reg[j] = gload16(base + (int64_t)(ok ? row : 0) * row_stride_bytes + (ok ? unit : 0) * 16);
   }
 }
-template <typename T>
-HSTU_DEV void solo_commit(const u32x4 (&reg)[4], char* tiles, int len, int real_d, int nt, int lane) {
+// TPT: tiles per tensor of the slice (2; 1 in the launches that take users of <= 32 rows only: a tensor's second tile does not exist there)
+template <typename T, int TPT = 2>
+HSTU_DEV void solo_commit(const u32x4 (&reg)[2 * TPT], char* tiles, int len, int real_d, int nt, int lane) {
   using S = SoloCfg<T>;
   constexpr int EPU = 16 / Elem<T>::kBytes;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 2 * TPT; ++j) {
     const int u = (j & 1) * 64 + lane, row = 32 * (j >> 1) + u / S::UPR, unit = u % S::UPR;
     const bool ok = (j >> 1) < nt && row < len && unit * EPU < real_d;
     *LDS_PTR(u32x4, tiles + (j >> 1) * S::TILE + tile_off<S::UPR>(u / S::UPR, unit)) = ok ? reg[j] : u32x4{0u, 0u, 0u, 0u};
   }
 }
-template <typename T>
+template <typename T, int TPT = 2>
 HSTU_DEV void solo_stage(char* tiles, const char* base, int64_t row_stride_bytes, int len, int real_d, int nt, int lane) {
-  u32x4 reg[4];
-  solo_issue<T>(reg, base, row_stride_bytes, len, real_d, nt, lane);
-  solo_commit<T>(reg, tiles, len, real_d, nt, lane);
+  u32x4 reg[2 * TPT];
+  solo_issue<T, TPT>(reg, base, row_stride_bytes, len, real_d, nt, lane);
+  solo_commit<T, TPT>(reg, tiles, len, real_d, nt, lane);
 }
 
 // rows of a parked [32][32] tile -> global (only the real head dim's units)
@@ -77,6 +78,16 @@ HSTU_DEV void solo_copy_out(const char* tile, char* gtile, int64_t row_stride_by
 HSTU_DEV int solo_mask_bits_fwd(const MaskCtx& mc, int i0, int j0, int lane) {
   const int n32 = lane & 31, hf = lane >> 5;
   const int qi = i0 + n32;
+  if (mc.simple) {
+    // plain causal (wave-uniform): bit r = key j0 + rho(r) <= query AND key < len AND query < len, rho(r) = (r&3) + 8 (r>>2) + 4 hf.
+    // The keys of a register set come in groups of four, eight apart: "rho(r) < m" is a run of whole groups and a partial one --
+    // a dozen instructions instead of the general predicate's ~250 (a third of a one-pair problem's instructions; Amazon-Books:
+    // every problem is one or three pairs).
+    const int m = min(min(qi + 1, mc.len) - j0, 32) - 4 * hf;       // keys of this lane's half below m survive
+    const int g = m >> 3, rem = min(m & 7, 4);
+    const int run = m <= 0 ? 0 : ((1 << (4 * g)) - 1) | (((1 << rem) - 1) << (4 * g));
+    return qi < mc.len ? (run & 0xffff) : 0;
+  }
   const int qi_id = mc.id_of(qi);
   int km = 0;
 #pragma unroll
@@ -98,13 +109,13 @@ HSTU_DEV SoloProb solo_prob(const HstuAttnParams& p, int uh) {
   r.len = min((int)(load_index(p.seq_offsets, r.b + 1, p.offsets_dtype) - r.off0), kSoloMaxLen);
   return r;
 }
-template <typename T>
-HSTU_DEV void solo_fwd_issue(const HstuAttnParams& p, const SoloProb& pr, u32x4 (&rk)[4], u32x4 (&rv)[4], u32x4 (&rq)[4], int lane) {
+template <typename T, int TPT = 2>
+HSTU_DEV void solo_fwd_issue(const HstuAttnParams& p, const SoloProb& pr, u32x4 (&rk)[2 * TPT], u32x4 (&rv)[2 * TPT], u32x4 (&rq)[2 * TPT], int lane) {
   constexpr int EB = Elem<T>::kBytes;
   const int nt = (pr.len + 31) >> 5;
-  solo_issue<T>(rk, (const char*)p.k + (pr.off0 * p.k_row_stride + (int64_t)pr.hd * p.k_head_stride) * EB, p.k_row_stride * EB, pr.len, p.dqk, nt, lane);
-  solo_issue<T>(rv, (const char*)p.v + (pr.off0 * p.v_row_stride + (int64_t)pr.hd * p.v_head_stride) * EB, p.v_row_stride * EB, pr.len, p.dv, nt, lane);
-  solo_issue<T>(rq, (const char*)p.q + (pr.off0 * p.q_row_stride + (int64_t)pr.hd * p.q_head_stride) * EB, p.q_row_stride * EB, pr.len, p.dqk, nt, lane);
+  solo_issue<T, TPT>(rk, (const char*)p.k + (pr.off0 * p.k_row_stride + (int64_t)pr.hd * p.k_head_stride) * EB, p.k_row_stride * EB, pr.len, p.dqk, nt, lane);
+  solo_issue<T, TPT>(rv, (const char*)p.v + (pr.off0 * p.v_row_stride + (int64_t)pr.hd * p.v_head_stride) * EB, p.v_row_stride * EB, pr.len, p.dv, nt, lane);
+  solo_issue<T, TPT>(rq, (const char*)p.q + (pr.off0 * p.q_row_stride + (int64_t)pr.hd * p.q_head_stride) * EB, p.q_row_stride * EB, pr.len, p.dqk, nt, lane);
 }
 
 // Time buckets of one user as BYTES in LDS, computed once per user by the workgroup's four waves and read by every head:
@@ -156,7 +167,7 @@ HSTU_DEV void solo_bucket_bytes(const BiasCtx& bc, char* bcache, int len, int wa
 // everything after the staging: the pairs of one problem from the wave's LDS slice, rows out.  BIAS: the research path's
 // relative position / time-bucket term (hstu_attn_fwd.cuh, BIAS) from the workgroup's staged tables.
 struct SoloNoBias {};
-template <typename T, bool BIAS = false, typename BC = SoloNoBias>
+template <typename T, bool BIAS = false, typename BC = SoloNoBias, int TPT = 2>
 HSTU_DEV void solo_fwd_compute(const HstuAttnParams& p, const SoloProb& pr, char* slice, int lane, const BC& bc = BC(),
                                const char* bcache = nullptr) {
   using S = SoloCfg<T>;
@@ -166,9 +177,9 @@ HSTU_DEV void solo_fwd_compute(const HstuAttnParams& p, const SoloProb& pr, char
   const int b = pr.b, hd = pr.hd, len = pr.len;
   const int64_t off0 = pr.off0;
   const MaskCtx mc = make_mask_ctx(p, b, len);
-  const int nt = (len + 31) >> 5;
+  const int nt = TPT == 1 ? 1 : (len + 31) >> 5;
   const int n32 = lane & 31, hf = lane >> 5;
-  char* Kt = slice, *Vt = slice + 2 * S::TILE, *Qt = slice + 4 * S::TILE;
+  char* Kt = slice, *Vt = slice + TPT * S::TILE, *Qt = slice + 2 * TPT * S::TILE;
   const float scale_v = attn_scale_of(p);
   const unsigned neg = __builtin_bit_cast(unsigned, p.alpha < 0.f ? 1e30f : -1e30f);
   for (int i = 0; i < nt; ++i) {
@@ -229,28 +240,30 @@ HSTU_DEV void solo_fwd_compute(const HstuAttnParams& p, const SoloProb& pr, char
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_kernel(const HstuAttnParams p) {
+// TPT = 1: the launch that takes the problems of <= 32 rows only (slices of one tile per tensor: 6 KiB per wave instead of 12 -- as many
+// workgroups per CU as the registers allow); the other launch takes the longer ones
+template <typename T, int TPT>
+__global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_kernel(const HstuAttnParams p, int len_lo, int len_hi) {
   using S = SoloCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slice = smem + wave * S::fwd_slice();
+  char* slice = smem + wave * S::fwd_slice(TPT);
   const int total = p.batch * p.heads;
   for (int uh = blockIdx.x * kSoloWaves + wave; uh < total; uh += gridDim.x * kSoloWaves) {
     int uh_l = uh;
     asm volatile("" : "+s"(uh_l));
     const SoloProb cur = solo_prob(p, uh_l);
-    if (cur.len <= 0) continue;
+    if (cur.len <= len_lo || cur.len > len_hi) continue;      // (empty, or the other launch's)
     // (issuing the NEXT problem's loads before computing this one -- 48 more live registers -- was measured: 56 -> 59 us
     // on the Amazon-Books batch; a wave's time per problem is instruction issue, not the HBM round trip)
-    u32x4 rk[4], rv[4], rq[4];
-    solo_fwd_issue<T>(p, cur, rk, rv, rq, lane);
+    u32x4 rk[2 * TPT], rv[2 * TPT], rq[2 * TPT];
+    solo_fwd_issue<T, TPT>(p, cur, rk, rv, rq, lane);
     const int nt = (cur.len + 31) >> 5;
-    solo_commit<T>(rk, slice, cur.len, p.dqk, nt, lane);
-    solo_commit<T>(rv, slice + 2 * S::TILE, cur.len, p.dv, nt, lane);
-    solo_commit<T>(rq, slice + 4 * S::TILE, cur.len, p.dqk, nt, lane);
-    solo_fwd_compute<T>(p, cur, slice, lane);
+    solo_commit<T, TPT>(rk, slice, cur.len, p.dqk, nt, lane);
+    solo_commit<T, TPT>(rv, slice + TPT * S::TILE, cur.len, p.dv, nt, lane);
+    solo_commit<T, TPT>(rq, slice + 2 * TPT * S::TILE, cur.len, p.dqk, nt, lane);
+    solo_fwd_compute<T, false, SoloNoBias, TPT>(p, cur, slice, lane);
   }
 }
 
@@ -303,24 +316,28 @@ HSTU_DEV SoloProb solo_user(const HstuAttnParams& p, int u, int hd) {      // u 
 // short-sequence kernel).  LDS per wave: slice + tables + 3 KiB of bucket bytes.  (A workgroup per user with its waves on
 // the heads, software-pipelined over the users as the backward below, was measured too: 143 vs 135 us on the Amazon-Books
 // batch.  By removal, of those 135-144 us the pairs are 71, the bucket bytes 37, the row loads 18, the rest 24.)
-template <typename T>
-__global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_bias_kernel(const HstuAttnParams p, int table_bytes) {
+#ifndef SOLO_FWD_BIAS_SHORT_WAVES
+#define SOLO_FWD_BIAS_SHORT_WAVES 3
+#endif
+template <typename T, int TPT>
+__global__ __launch_bounds__(kSoloThreads) __attribute__((amdgpu_waves_per_eu(TPT == 1 ? SOLO_FWD_BIAS_SHORT_WAVES : 2, TPT == 1 ? SOLO_FWD_BIAS_SHORT_WAVES : 2)))
+void hstu_attn_fwd_solo_bias_kernel(const HstuAttnParams p, int table_bytes, int len_lo, int len_hi) {
   using S = SoloCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int per_wave = S::fwd_slice() + table_bytes + kSoloBucketBytes;
+  const int per_wave = S::fwd_slice(TPT) + table_bytes + (TPT == 1 ? 1024 : kSoloBucketBytes);
   char* slice = smem + wave * per_wave;
-  char* const tables = slice + S::fwd_slice();
+  char* const tables = slice + S::fwd_slice(TPT);
   char* const bcache = tables + table_bytes;
   bool first = true;
   for (int u = blockIdx.x * kSoloWaves + wave; u < p.batch; u += gridDim.x * kSoloWaves) {
     int u_l = u;
     asm volatile("" : "+s"(u_l));
     SoloProb cur = solo_user(p, u_l, 0);
-    if (cur.len <= 0) continue;
-    u32x4 rk[4], rv[4], rq[4];
-    solo_fwd_issue<T>(p, cur, rk, rv, rq, lane);                    // head 0: under the staging of the user's tables
+    if (cur.len <= len_lo || cur.len > len_hi) continue;      // (empty, or the other launch's)
+    u32x4 rk[2 * TPT], rv[2 * TPT], rq[2 * TPT];
+    solo_fwd_issue<T, TPT>(p, cur, rk, rv, rq, lane);                // head 0: under the staging of the user's tables
     BiasCtx bc = stage_bias_tables(p, cur.b, tables, lane, 64, !first);
     first = false;
     bc.finish(1);                                                    // (LDS operations of a wave complete in order: no barrier)
@@ -328,15 +345,15 @@ __global__ __launch_bounds__(kSoloThreads) void hstu_attn_fwd_solo_bias_kernel(c
     const int nt = (cur.len + 31) >> 5;
     for (int hd = 0; hd < p.heads; ++hd) {
       cur.hd = hd;
-      solo_commit<T>(rk, slice, cur.len, p.dqk, nt, lane);
-      solo_commit<T>(rv, slice + 2 * S::TILE, cur.len, p.dv, nt, lane);
-      solo_commit<T>(rq, slice + 4 * S::TILE, cur.len, p.dqk, nt, lane);
+      solo_commit<T, TPT>(rk, slice, cur.len, p.dqk, nt, lane);
+      solo_commit<T, TPT>(rv, slice + TPT * S::TILE, cur.len, p.dv, nt, lane);
+      solo_commit<T, TPT>(rq, slice + 2 * TPT * S::TILE, cur.len, p.dqk, nt, lane);
       if (hd + 1 < p.heads) {                                        // the next head's rows: in flight during this head's pairs
         SoloProb nx = cur;
         nx.hd = hd + 1;
-        solo_fwd_issue<T>(p, nx, rk, rv, rq, lane);
+        solo_fwd_issue<T, TPT>(p, nx, rk, rv, rq, lane);
       }
-      solo_fwd_compute<T, true, BiasCtx>(p, cur, slice, lane, bc, bcache);
+      solo_fwd_compute<T, true, BiasCtx, TPT>(p, cur, slice, lane, bc, bcache);
     }
   }
 }
@@ -374,58 +391,59 @@ HSTU_DEV void solo_dq(const HstuAttnBwdParams& bp, const MaskCtx& mc, const char
 }
 
 // the four row blocks of one (user, head): requested (registers) / written to the wave's slice
-template <typename T>
-HSTU_DEV void solo_bwd_issue(const HstuAttnBwdParams& bp, const SoloProb& pr, u32x4 (&rk)[4], u32x4 (&rv)[4], u32x4 (&rq)[4], u32x4 (&rd)[4], int lane) {
+template <typename T, int TPT = 2>
+HSTU_DEV void solo_bwd_issue(const HstuAttnBwdParams& bp, const SoloProb& pr, u32x4 (&rk)[2 * TPT], u32x4 (&rv)[2 * TPT], u32x4 (&rq)[2 * TPT],
+                             u32x4 (&rd)[2 * TPT], int lane) {
   constexpr int EB = Elem<T>::kBytes;
   const HstuAttnParams& p = bp.fwd;
   const int nt = (pr.len + 31) >> 5;
-  solo_issue<T>(rk, (const char*)p.k + (pr.off0 * p.k_row_stride + (int64_t)pr.hd * p.k_head_stride) * EB, p.k_row_stride * EB, pr.len, p.dqk, nt, lane);
-  solo_issue<T>(rv, (const char*)p.v + (pr.off0 * p.v_row_stride + (int64_t)pr.hd * p.v_head_stride) * EB, p.v_row_stride * EB, pr.len, p.dv, nt, lane);
-  solo_issue<T>(rq, (const char*)p.q + (pr.off0 * p.q_row_stride + (int64_t)pr.hd * p.q_head_stride) * EB, p.q_row_stride * EB, pr.len, p.dqk, nt, lane);
-  solo_issue<T>(rd, (const char*)bp.dout + (pr.off0 * bp.do_row_stride + (int64_t)pr.hd * bp.do_head_stride) * EB, bp.do_row_stride * EB, pr.len, p.dv, nt, lane);
+  solo_issue<T, TPT>(rk, (const char*)p.k + (pr.off0 * p.k_row_stride + (int64_t)pr.hd * p.k_head_stride) * EB, p.k_row_stride * EB, pr.len, p.dqk, nt, lane);
+  solo_issue<T, TPT>(rv, (const char*)p.v + (pr.off0 * p.v_row_stride + (int64_t)pr.hd * p.v_head_stride) * EB, p.v_row_stride * EB, pr.len, p.dv, nt, lane);
+  solo_issue<T, TPT>(rq, (const char*)p.q + (pr.off0 * p.q_row_stride + (int64_t)pr.hd * p.q_head_stride) * EB, p.q_row_stride * EB, pr.len, p.dqk, nt, lane);
+  solo_issue<T, TPT>(rd, (const char*)bp.dout + (pr.off0 * bp.do_row_stride + (int64_t)pr.hd * bp.do_head_stride) * EB, bp.do_row_stride * EB, pr.len, p.dv, nt, lane);
 }
-template <typename T>
-HSTU_DEV void solo_bwd_commit(const HstuAttnBwdParams& bp, const SoloProb& pr, const u32x4 (&rk)[4], const u32x4 (&rv)[4], const u32x4 (&rq)[4],
-                              const u32x4 (&rd)[4], char* slice, int lane) {
+template <typename T, int TPT = 2>
+HSTU_DEV void solo_bwd_commit(const HstuAttnBwdParams& bp, const SoloProb& pr, const u32x4 (&rk)[2 * TPT], const u32x4 (&rv)[2 * TPT],
+                              const u32x4 (&rq)[2 * TPT], const u32x4 (&rd)[2 * TPT], char* slice, int lane) {
   using S = SoloCfg<T>;
   const HstuAttnParams& p = bp.fwd;
   const int nt = (pr.len + 31) >> 5;
-  solo_commit<T>(rk, slice, pr.len, p.dqk, nt, lane);
-  solo_commit<T>(rv, slice + 2 * S::TILE, pr.len, p.dv, nt, lane);
-  solo_commit<T>(rq, slice + 4 * S::TILE, pr.len, p.dqk, nt, lane);
-  solo_commit<T>(rd, slice + 6 * S::TILE, pr.len, p.dv, nt, lane);
+  solo_commit<T, TPT>(rk, slice, pr.len, p.dqk, nt, lane);
+  solo_commit<T, TPT>(rv, slice + TPT * S::TILE, pr.len, p.dv, nt, lane);
+  solo_commit<T, TPT>(rq, slice + 2 * TPT * S::TILE, pr.len, p.dqk, nt, lane);
+  solo_commit<T, TPT>(rd, slice + 3 * TPT * S::TILE, pr.len, p.dv, nt, lane);
 }
-template <typename T>
+template <typename T, int TPT = 2>
 HSTU_DEV void solo_bwd_stage(const HstuAttnBwdParams& bp, int b, int hd, char* slice, int lane) {
   using S = SoloCfg<T>;
   constexpr int EB = Elem<T>::kBytes;
   const HstuAttnParams& p = bp.fwd;
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
-  const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), kSoloMaxLen);
+  const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), 32 * TPT);
   if (len <= 0) return;
   const int nt = (len + 31) >> 5;
-  char* Kt = slice, *Vt = slice + 2 * S::TILE, *Qt = slice + 4 * S::TILE, *dOt = slice + 6 * S::TILE;
-  solo_stage<T>(Kt, (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * EB, p.k_row_stride * EB, len, p.dqk, nt, lane);
-  solo_stage<T>(Vt, (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * EB, p.v_row_stride * EB, len, p.dv, nt, lane);
-  solo_stage<T>(Qt, (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * EB, p.q_row_stride * EB, len, p.dqk, nt, lane);
-  solo_stage<T>(dOt, (const char*)bp.dout + (off0 * bp.do_row_stride + (int64_t)hd * bp.do_head_stride) * EB, bp.do_row_stride * EB, len, p.dv, nt, lane);
+  char* Kt = slice, *Vt = slice + TPT * S::TILE, *Qt = slice + 2 * TPT * S::TILE, *dOt = slice + 3 * TPT * S::TILE;
+  solo_stage<T, TPT>(Kt, (const char*)p.k + (off0 * p.k_row_stride + (int64_t)hd * p.k_head_stride) * EB, p.k_row_stride * EB, len, p.dqk, nt, lane);
+  solo_stage<T, TPT>(Vt, (const char*)p.v + (off0 * p.v_row_stride + (int64_t)hd * p.v_head_stride) * EB, p.v_row_stride * EB, len, p.dv, nt, lane);
+  solo_stage<T, TPT>(Qt, (const char*)p.q + (off0 * p.q_row_stride + (int64_t)hd * p.q_head_stride) * EB, p.q_row_stride * EB, len, p.dqk, nt, lane);
+  solo_stage<T, TPT>(dOt, (const char*)bp.dout + (off0 * bp.do_row_stride + (int64_t)hd * bp.do_head_stride) * EB, bp.do_row_stride * EB, len, p.dv, nt, lane);
 }
 
 // `staged`: the caller has run solo_bwd_stage for this problem already
-template <typename T, typename BX = FoldNoBias>
+template <typename T, typename BX = FoldNoBias, int TPT = 2>
 HSTU_DEV void solo_bwd_problem_x(const HstuAttnBwdParams& bp, int b, int hd, char* slice, int lane, BX& bx, bool staged = false) {
   using S = SoloCfg<T>;
   using C = BwdCfg<T, kSoloD, kSoloD>;
   constexpr int EB = Elem<T>::kBytes;
   const HstuAttnParams& p = bp.fwd;
   const int64_t off0 = load_index(p.seq_offsets, b, p.offsets_dtype);
-  const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), kSoloMaxLen);
+  const int len = min((int)(load_index(p.seq_offsets, b + 1, p.offsets_dtype) - off0), 32 * TPT);
   if (len <= 0) return;
   const MaskCtx mc = make_mask_ctx(p, b, len);
   HSTU_TRACE_DECL(bp.workspace, false);
-  const int nt = (len + 31) >> 5;
-  char* Kt = slice, *Vt = slice + 2 * S::TILE, *Qt = slice + 4 * S::TILE, *dOt = slice + 6 * S::TILE, *ds = slice + 8 * S::TILE;
-  if (!staged) solo_bwd_stage<T>(bp, b, hd, slice, lane);
+  const int nt = TPT == 1 ? 1 : (len + 31) >> 5;
+  char* Kt = slice, *Vt = slice + TPT * S::TILE, *Qt = slice + 2 * TPT * S::TILE, *dOt = slice + 3 * TPT * S::TILE, *ds = slice + 4 * TPT * S::TILE;
+  if (!staged) solo_bwd_stage<T, TPT>(bp, b, hd, slice, lane);
   f32x16 dk0[1], dv0[1], dk1[1], dv1[1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk0[0][r] = 0.f; dv0[0][r] = 0.f; dk1[0][r] = 0.f; dv1[0][r] = 0.f; }
@@ -442,7 +460,7 @@ HSTU_DEV void solo_bwd_problem_x(const HstuAttnBwdParams& bp, int b, int hd, cha
     }
   }
   for (int i = nt - 1; i >= 0; --i) {
-    if (i >= 1 && (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 32, 32)))
+    if (TPT > 1 && i >= 1 && (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 32, 32)))
       fold_pair_x<T, kSoloD, kSoloD, BX>(p, mc, Kt + S::TILE, Vt + S::TILE, Qt + i * S::TILE, dOt + i * S::TILE, ds + 32 * 64, 32 * i, 32, dk1, dv1,
                                          lane, dmvm, bx HSTU_TRACE_PASS);
     if (mc.win == 0 || mc.pair_may_be_active(32 * i, 32, 0, 32))
@@ -457,7 +475,7 @@ HSTU_DEV void solo_bwd_problem_x(const HstuAttnBwdParams& bp, int b, int hd, cha
   fold_park_tile<T, kSoloD>(dv0, scale_v, Vt, lane);
   solo_copy_out<T>(Kt, dk_head, bp.dk_row_stride * EB, len, p.dqk, lane);
   solo_copy_out<T>(Vt, dv_head, bp.dv_row_stride * EB, len, p.dv, lane);
-  if (nt > 1) {
+  if (TPT > 1 && nt > 1) {
     fold_park_tile<T, kSoloD>(dk1, ds_scale, Kt + S::TILE, lane);
     fold_park_tile<T, kSoloD>(dv1, scale_v, Vt + S::TILE, lane);
     solo_copy_out<T>(Kt + S::TILE, dk_head + 32 * bp.dk_row_stride * EB, bp.dk_row_stride * EB, len - 32, p.dqk, lane);
@@ -465,32 +483,54 @@ HSTU_DEV void solo_bwd_problem_x(const HstuAttnBwdParams& bp, int b, int hd, cha
   }
   (void)C::EB;
 }
-template <typename T>
-HSTU_DEV void solo_bwd_problem(const HstuAttnBwdParams& bp, int uh, char* slice, int lane) {
-  FoldNoBias nb;
-  solo_bwd_problem_x<T, FoldNoBias>(bp, user_of_slot(bp.fwd, uh / bp.fwd.heads), uh % bp.fwd.heads, slice, lane, nb);
-}
-
 // Research-path backward at the short-sequence shapes: as the forward above -- the workgroup walks users, its waves the
 // heads -- with the bias term and the two histograms of dS' of the folded research kernel (fold_pair_x<FoldBias>): ONE pair of
 // LDS histograms per workgroup for everything it processes, flushed to its row of `bias_partial` at the end; the user's
 // bucket bytes computed once by the four waves (fold_pair_x then always reads its byte cache).
-// LDS: [4 slices][pos histogram 2N | time histogram (nb+1) x ts_copies][2 x (tables | 3 KiB bucket bytes)].
-template <typename T>
-__global__ __launch_bounds__(kSoloThreads) void hstu_attn_bwd_solo_bias_kernel(const HstuAttnBwdParams bp, float* bias_partial, int ts_copies,
-                                                                              int hist_bytes, int table_bytes) {
+// LDS: [4 slices][pos histogram 2N | time histogram (nb+1) x ts_copies][2 x (tables | bucket bytes)].
+//
+// Round 6: TWO launches by length class.  A slice sized for 64 rows (20 KiB per wave) left room for one workgroup per CU -- one wave
+// per SIMD, every latency of a user's chain exposed, two workgroup barriers per user with nothing else on the CU -- while 95 % of an
+// Amazon-Books batch is shorter than 33 rows.  The launch that takes the users of <= 32 rows lays its slices out with ONE tile per
+// tensor (`tpt` = 1: 10 KiB per wave, 1 KiB of bucket bytes): two independent workgroups per CU (the lesson of every experiment of
+// rounds 4-6: independent workgroups hide each other's latencies, a lone lock-stepped one hides nothing); the other launch takes the
+// users of 33 .. 64 rows as before.  A launch walks the whole launch order and skips the users of the other class (offsets through
+// scalar loads: no wait on the prefetched rows).  `row0`: first row of `bias_partial` of this launch.
+struct SoloSlot { SoloProb pr; int slot; };
+HSTU_DEV SoloSlot solo_next_user(const HstuAttnParams& p, int slot, int stride, int hd, int len_lo, int len_hi) {
+  SoloSlot r;
+  r.pr.b = 0; r.pr.hd = hd; r.pr.off0 = 0; r.pr.len = 0;
+  for (; slot < p.batch; slot += stride) {
+    r.pr.b = user_of_slot_s(p, slot);
+    r.pr.off0 = sload_index(p.seq_offsets, r.pr.b, p.offsets_dtype);
+    r.pr.len = min((int)(sload_index(p.seq_offsets, r.pr.b + 1, p.offsets_dtype) - r.pr.off0), kSoloMaxLen);
+    if (r.pr.len > len_lo && r.pr.len <= len_hi) break;
+  }
+  if (slot >= p.batch) {      // none left: a harmless problem (every load of it is a valid one, nothing is computed for it)
+    r.pr.b = user_of_slot_s(p, 0);
+    r.pr.off0 = sload_index(p.seq_offsets, r.pr.b, p.offsets_dtype);
+    r.pr.len = 0;
+  }
+  r.slot = slot;
+  return r;
+}
+
+template <typename T, int TPT>
+__global__ __launch_bounds__(kSoloThreads) __attribute__((amdgpu_waves_per_eu(TPT == 1 ? 2 : 1, TPT == 1 ? 2 : 1))) void hstu_attn_bwd_solo_bias_kernel(
+    const HstuAttnBwdParams bp, float* bias_partial, int ts_copies, int hist_bytes, int table_bytes, int len_lo, int len_hi, int row0) {
   using S = SoloCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const HstuAttnParams& p = bp.fwd;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* slice = smem + wave * S::bwd_slice();
+  constexpr int slice_bytes = S::bwd_slice(TPT);
+  char* slice = smem + wave * slice_bytes;
   FoldBias bx;
-  bx.hpos = (float*)(smem + kSoloWaves * S::bwd_slice());
+  bx.hpos = (float*)(smem + kSoloWaves * slice_bytes);
   bx.hts = bx.hpos + 2 * p.max_seq_len;
   char* const tab0 = (char*)bx.hpos + hist_bytes;
-  const int tab_stride = table_bytes + kSoloBucketBytes;
+  const int tab_stride = table_bytes + (TPT == 1 ? 1024 : kSoloBucketBytes);
   bx.ts_run.init(bx.hts, ts_copies);
   bx.cached = true;
   const int hist_floats = 2 * p.max_seq_len + (p.num_buckets + 1) * ts_copies;
@@ -498,33 +538,34 @@ __global__ __launch_bounds__(kSoloThreads) void hstu_attn_bwd_solo_bias_kernel(c
   const int hd0 = min(wave, p.heads - 1);
   const int grid = gridDim.x;
   {
-    const int b0 = user_of_slot(p, blockIdx.x);
+    const int b0 = user_of_slot(p, min((int)blockIdx.x, p.batch - 1));
     stage_bias_tables(p, b0, tab0, tid, kSoloThreads);
     stage_bias_tables(p, b0, tab0 + tab_stride, tid, kSoloThreads);
   }
   // the same software pipeline over the users as the forward kernel: rows / timestamps of the next user, offsets of the
   // one after, requested while this one is worked on; tables and bucket bytes double-buffered
-  SoloProb cur = solo_user(p, blockIdx.x, hd0), nxt = solo_user(p, blockIdx.x + grid, hd0);
-  u32x4 rk[4], rv[4], rq[4], rd[4];
+  SoloSlot cur = solo_next_user(p, blockIdx.x, grid, hd0, len_lo, len_hi);
+  SoloSlot nxt = solo_next_user(p, cur.slot + grid, grid, hd0, len_lo, len_hi);
+  u32x4 rk[2 * TPT], rv[2 * TPT], rq[2 * TPT], rd[2 * TPT];
   SoloTs ts = {0, 0, 0, 0};
-  solo_bwd_issue<T>(bp, cur, rk, rv, rq, rd, lane);
-  solo_ts_issue(p, cur.b, tid, ts);
+  solo_bwd_issue<T, TPT>(bp, cur.pr, rk, rv, rq, rd, lane);
+  solo_ts_issue(p, cur.pr.b, tid, ts);
   __syncthreads();                         // histograms zeroed, tables in place
   int buf = 0;
-  for (int u = blockIdx.x; u < p.batch; u += grid) {
+  while (cur.slot < p.batch) {
     char* const tables = tab0 + buf * tab_stride;
     bx.bcache = tables + table_bytes;
-    solo_bwd_commit<T>(bp, cur, rk, rv, rq, rd, slice, lane);
+    solo_bwd_commit<T, TPT>(bp, cur.pr, rk, rv, rq, rd, slice, lane);
     bx.bc = solo_ts_commit(p, tables, tid, ts);
-    const SoloProb pf = (u + grid < p.batch) ? nxt : cur;
-    solo_bwd_issue<T>(bp, pf, rk, rv, rq, rd, lane);
+    const SoloProb pf = nxt.slot < p.batch ? nxt.pr : cur.pr;
+    solo_bwd_issue<T, TPT>(bp, pf, rk, rv, rq, rd, lane);
     solo_ts_issue(p, pf.b, tid, ts);
-    const SoloProb nn = solo_user(p, u + 2 * grid, hd0);
+    const SoloSlot nn = solo_next_user(p, nxt.slot + grid, grid, hd0, len_lo, len_hi);
     __syncthreads();
     bx.bc.finish(kSoloWaves);
-    solo_bucket_bytes<true>(bx.bc, bx.bcache, cur.len, wave, lane);
+    solo_bucket_bytes<true>(bx.bc, bx.bcache, cur.pr.len, wave, lane);
     __syncthreads();
-    for (int hd = wave; hd < p.heads; hd += kSoloWaves) solo_bwd_problem_x<T, FoldBias>(bp, cur.b, hd, slice, lane, bx, hd == wave);
+    for (int hd = wave; hd < p.heads; hd += kSoloWaves) solo_bwd_problem_x<T, FoldBias, TPT>(bp, cur.pr.b, hd, slice, lane, bx, hd == wave);
     cur = nxt;
     nxt = nn;
     buf ^= 1;
@@ -532,7 +573,7 @@ __global__ __launch_bounds__(kSoloThreads) void hstu_attn_bwd_solo_bias_kernel(c
   bx.ts_run.flush();
   __syncthreads();
   const float scale_v = attn_scale_of(p);
-  float* row = bias_partial + (int64_t)blockIdx.x * (2 * p.max_seq_len + p.num_buckets);
+  float* row = bias_partial + (int64_t)(row0 + (int)blockIdx.x) * (2 * p.max_seq_len + p.num_buckets);
   const int npos = 2 * p.max_seq_len - 1;
   for (int i = tid; i < 2 * p.max_seq_len + p.num_buckets; i += kSoloThreads) {
     float v;
@@ -547,17 +588,29 @@ __global__ __launch_bounds__(kSoloThreads) void hstu_attn_bwd_solo_bias_kernel(c
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kSoloThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void hstu_attn_bwd_solo_kernel(const HstuAttnBwdParams bp) {
+// TPT = 1: the launch that takes the (user, head) problems of <= 32 rows only -- slices of one tile per tensor (10 KiB per wave instead of
+// 20), half the accumulators and staging registers (128 instead of 213): four workgroups per CU instead of two (the other launch takes
+// the longer users)
+#ifndef SOLO_BWD_SHORT_WAVES
+#define SOLO_BWD_SHORT_WAVES 4
+#endif
+template <typename T, int TPT>
+__global__ __launch_bounds__(kSoloThreads) __attribute__((amdgpu_waves_per_eu(TPT == 1 ? SOLO_BWD_SHORT_WAVES : 2, TPT == 1 ? SOLO_BWD_SHORT_WAVES : 2)))
+void hstu_attn_bwd_solo_kernel(const HstuAttnBwdParams bp, int len_lo, int len_hi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* slice = smem + wave * SoloCfg<T>::bwd_slice();
-  const int total = bp.fwd.batch * bp.fwd.heads;
+  char* slice = smem + wave * SoloCfg<T>::bwd_slice(TPT);
+  const HstuAttnParams& p = bp.fwd;
+  const int total = p.batch * p.heads;
   for (int uh = blockIdx.x * kSoloWaves + wave; uh < total; uh += gridDim.x * kSoloWaves) {
     int uh_l = uh;
     asm volatile("" : "+s"(uh_l));
-    solo_bwd_problem<T>(bp, uh_l, slice, lane);
+    const int b = user_of_slot_s(p, uh_l / p.heads);
+    const int len = min((int)(sload_index(p.seq_offsets, b + 1, p.offsets_dtype) - sload_index(p.seq_offsets, b, p.offsets_dtype)), kSoloMaxLen);
+    if (len <= len_lo || len > len_hi) continue;       // (the other launch's)
+    FoldNoBias nb;
+    solo_bwd_problem_x<T, FoldNoBias, TPT>(bp, b, uh_l % p.heads, slice, lane, nb);
   }
 }
 
