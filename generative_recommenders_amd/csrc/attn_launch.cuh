@@ -110,9 +110,12 @@ static int launch_bwd_fold_bias_inst(const HstuAttnBwdParams& bp, hipStream_t st
   const int grid = p.batch < n_cu ? p.batch : n_cu;
   const int hw = 2 * p.max_seq_len + p.num_buckets;
   float* partial = (float*)bp.workspace;
-  e = hipMemsetAsync(partial, 0, (size_t)grid * hw * sizeof(float), st);
+  // (the user counter of the dynamic hand-out sits right behind the partial rows, in the first word of the region the reduce's chunk sums
+  // take over AFTER this kernel: one memset zeroes both)
+  int* const next_user = (int*)(partial + (size_t)grid * hw);
+  e = hipMemsetAsync(partial, 0, ((size_t)grid * hw + 1) * sizeof(float), st);
   if (e != hipSuccess) return set_error(HSTU_ELAUNCH, "hstu_attn_bwd: workspace memset failed: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), smem, st, bp, tmax, partial, ts_copies, hist, tables);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), smem, st, bp, tmax, partial, ts_copies, hist, tables, next_user);
   if (int rc = check_launch("hstu_attn_bwd(fold, bias)")) return rc;
   return launch_bias_grad_reduce(partial, grid, hw, 2 * p.max_seq_len - 1, bp.dpos_w, bp.dts_w, st);
 }

@@ -974,7 +974,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
 // LDS behind the folded kernel's own region: [pos histogram 2N][time histogram (nb+1) x ts_copies][tables][bucket bytes].
 template <typename T, int D>
 __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void hstu_attn_bwd_fold_bias_kernel(
-    const HstuAttnBwdParams bp_arg, int tmax, float* bias_partial, int ts_copies, int hist_bytes, int table_bytes) {
+    const HstuAttnBwdParams bp_arg, int tmax, float* bias_partial, int ts_copies, int hist_bytes, int table_bytes, int* next_user) {
   using F = FoldCfg<T, D, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -998,7 +998,14 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     const HstuAttnBwdParams bp0 = reload_bwd_params(kargs);
     cur = fold_work(bp0.fwd, (int)blockIdx.x * heads, tmax);
   }
-  for (int u = blockIdx.x; u < batch; u += gridDim.x) {
+  // Users are handed out DYNAMICALLY (round 6): workgroup b starts with user b of the launch order and takes its next one from a
+  // counter (`next_user`, zeroed by the launcher; thread 0 adds, the value crosses the workgroup in the unused last word of the position
+  // histogram, between the two barriers every user has anyway).  Walking users b, b + grid, ... left the launch waiting for whichever
+  // workgroup had drawn the longest users: ML-20M lengths (uniform in 1 .. 211), 8192 users: 2.78 ms, the SAME batch with its users
+  // sorted by length 2.38 (tools/c2_length_order_probe.py).
+  volatile int* const slot = (volatile int*)(bx.hpos + 2 * max_seq_len - 1);
+  for (int u = blockIdx.x; u < batch;) {
+    if (tid == 0) *slot = (int)gridDim.x + atomicAdd(next_user, 1);
     __syncthreads();                       // the previous user's pairs have read their last table entry
     {
       kargw_t kl = kargs;
@@ -1008,12 +1015,13 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     }
     __syncthreads();
     bx.bc.finish(kBwdWaves);
+    const int u_next = __builtin_amdgcn_readfirstlane(*slot);      // (rewritten only behind the barriers of the head loop below)
     for (int hd = 0; hd < heads; ++hd) {
       kargw_t kl = kargs;
       asm volatile("" : "+s"(kl));
       const HstuAttnBwdParams bp = reload_bwd_params(kl);
       const int uh = u * heads + hd;
-      const int uh_n = hd + 1 < heads ? uh + 1 : (u + (int)gridDim.x < batch ? (u + (int)gridDim.x) * heads : -1);
+      const int uh_n = hd + 1 < heads ? uh + 1 : (u_next < batch ? u_next * heads : -1);
       FoldWork nxt;
       nxt.len = 0; nxt.off0 = 0; nxt.b = 0; nxt.hd = 0;
       if (hd + 1 < heads) { nxt = cur; nxt.hd = hd + 1; }            // the same user's next head: no load
@@ -1023,6 +1031,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
       cur = nxt;
       __syncthreads();
     }
+    u = u_next;
   }
   bx.ts_run.flush();
   __syncthreads();
