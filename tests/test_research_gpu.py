@@ -160,6 +160,46 @@ def test_folded_bias_backward_many_users_per_workgroup(dtype, H, n, B):
     _close(ts_w.grad, rts, 2e-3, 1e-4, f"dts_w[{tag} folded]")
 
 
+@pytest.mark.parametrize("d,n,B", [(64, 211, 1500), (16, 61, 3000)])
+def test_results_do_not_depend_on_the_launch_order_or_the_hand_out(d, n, B, monkeypatch):
+    """Round 6: the research attention launches heavy users first (from 512 users on) and its persistent backward kernels hand users
+    out from a counter / in two launches by length class -- who computes a user may differ from run to run, what is computed may not:
+    out, dq, dk, dv bit-identical with and without the order and run to run; the table gradients (float atomics into histograms,
+    summed per workgroup) to 1e-5 of their norm."""
+    m = _mods()
+    H, dtype = 4, torch.bfloat16
+    rng = np.random.default_rng(B + n)
+    lengths = rng.integers(0, n + 1, size=B)
+    lengths[rng.integers(0, B, size=B // 20)] = n
+    off = O.complete_cumsum(lengths.astype(np.int64))
+    Lt = int(off[-1])
+    ts = np.sort(rng.integers(0, 10 ** 8, size=(B, n)), axis=1)
+    mk = lambda: torch.from_numpy(rng.standard_normal((Lt, H * d)) * 0.3).to(dtype).to(DEV)
+    q, k, v, g = mk(), mk(), mk(), mk()
+    bias = m.RelativeBucketedTimeAndPositionBasedBias(n, 128).to(DEV)
+    with torch.no_grad():
+        bias._ts_w.normal_(0, 0.05)
+        bias._pos_w.normal_(0, 0.05)
+    offd, tsd = torch.from_numpy(off).to(DEV), torch.from_numpy(ts).to(DEV)
+
+    def run():
+        qd, kd, vd = (t.clone().requires_grad_() for t in (q, k, v))
+        bias.zero_grad()
+        out = m.hstu_rel_bias_attention(H, d, d, qd, kd, vd, offd, tsd, n, bias)
+        out.backward(g)
+        return [out.detach(), qd.grad, kd.grad, vd.grad], [bias._pos_w.grad.clone(), bias._ts_w.grad.clone()]
+
+    a, ta = run()
+    b, tb = run()
+    monkeypatch.setattr(m, "_ORDER_MIN_USERS", 10 ** 9)       # batch order
+    c, tc = run()
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    for x, y, z in zip(ta, tb, tc):
+        den = float(x.double().norm())
+        assert float((x.double() - y.double()).norm()) <= 1e-5 * den and float((x.double() - z.double()).norm()) <= 1e-5 * den
+
+
 @pytest.mark.parametrize("dtype,H,d,n,B,with_ts", [(torch.bfloat16, 4, 16, 61, 700, True), (torch.float16, 6, 32, 64, 300, True),
                                                     (torch.bfloat16, 1, 8, 17, 500, True), (torch.bfloat16, 3, 24, 33, 400, False),
                                                     (torch.bfloat16, 2, 16, 61, 3, True)])

@@ -78,6 +78,10 @@ def main():
                 c["WRITE_SIZE"] += summ[cand[0]]["WRITE_SIZE"]
             if missing:
                 continue
+            # the short-sequence backward kernels run as TWO dispatches per step (length classes, round 6): the summary's average per
+            # dispatch is half a step's bytes
+            if side == "bwd" and "solo" in full and os.environ.get("HSTU_SOLO_SPLIT", "1") != "0" and n > 32:
+                c = {k: 2.0 * v for k, v in c.items()}
             ent[side] = {"kernel": full, "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
                          "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
                          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, average per dispatch; bytes = (2 x FETCH_SIZE + "

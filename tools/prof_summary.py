@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("hstu_ln_linear_fwd_kernel", "Cijk_", "hstu_attn_bwd_dkv_kernel", "hstu_attn_bwd_dq_kernel", "hstu_attn_bwd_fold_bias_kernel", "hstu_attn_bwd_fold_kernel", "hstu_attn_bwd_quad_kernel", "hstu_attn_bwd_solo_kernel",
+    for key in ("hstu_ln_linear_fwd_kernel", "Cijk_", "hstu_attn_bwd_dkv_kernel", "hstu_attn_bwd_dq_kernel", "hstu_attn_bwd_fold_bias_kernel", "hstu_attn_bwd_fold_kernel", "hstu_attn_bwd_quad_kernel", "hstu_attn_bwd_solo_bias_kernel", "hstu_attn_fwd_solo_bias_kernel", "hstu_attn_bwd_solo_kernel",
                 "hstu_attn_fwd_solo_kernel", "hstu_attn_bwd_kernel", "hstu_attn_fwd_kernel", "hstu_dq_convert", "layer_norm", "norm_mul", "silu"):
         if key in name:
             return key
