@@ -956,12 +956,25 @@ class _StdoutToStderr:
         os.dup2(2, 1)
         return self
 
+    @staticmethod
+    def _flush_c_stdio():
+        # (C stdio is fully buffered into a pipe or a file: what RCCL printf'ed would otherwise leave at process exit -- AFTER descriptor
+        # 1 is back in place, i.e. behind the JSON line on stdout)
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     def emit(self, text):
         sys.stdout.flush()
+        self._flush_c_stdio()
         os.write(self.saved, (text + "\n").encode())
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c_stdio()
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
