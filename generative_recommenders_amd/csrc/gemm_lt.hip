@@ -91,6 +91,18 @@ int addmm_lt(const void* c, int64_t ldc, const void* a, int64_t lda, const void*
     return set_error(HSTU_ELAUNCH, "hstu_addmm_residual: hipblasLtCreate failed");
   }
   const Key key{dev, m, n, k, lda, ldb, ldc, ldd, dtype, workspace_bytes};
+  // (jagged batches: the row count m changes from call to call, and so does the planned problem -- the cache is bounded: emptied, with
+  // its descriptors destroyed, when it has grown to kMaxPlans; planning a problem is what torch's own wrapper does on EVERY call)
+  constexpr size_t kMaxPlans = 256;
+  if (g_plans.size() >= kMaxPlans && g_plans.find(key) == g_plans.end()) {
+    for (auto& kv : g_plans) {
+      Plan& q = kv.second;
+      if (q.desc) api.desc_destroy(q.desc);
+      for (hipblasLtMatrixLayout_t l : {q.la, q.lb, q.lc, q.ld})
+        if (l) api.layout_destroy(l);
+    }
+    g_plans.clear();
+  }
   Plan& pl = g_plans[key];
   if (!pl.ok) {
     if (api.desc_create(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS ||
@@ -98,6 +110,9 @@ int addmm_lt(const void* c, int64_t ldc, const void* a, int64_t lda, const void*
         api.layout_create(&pl.lb, ty, (uint64_t)k, (uint64_t)m, lda) != HIPBLAS_STATUS_SUCCESS ||
         api.layout_create(&pl.lc, ty, (uint64_t)n, (uint64_t)m, ldc) != HIPBLAS_STATUS_SUCCESS ||
         api.layout_create(&pl.ld, ty, (uint64_t)n, (uint64_t)m, ldd) != HIPBLAS_STATUS_SUCCESS) {
+      if (pl.desc) api.desc_destroy(pl.desc);
+      for (hipblasLtMatrixLayout_t l : {pl.la, pl.lb, pl.lc, pl.ld})
+        if (l) api.layout_destroy(l);
       g_plans.erase(key);
       return set_error(HSTU_ELAUNCH, "hstu_addmm_residual: hipBLASLt descriptors could not be created");
     }
@@ -111,6 +126,8 @@ int addmm_lt(const void* c, int64_t ldc, const void* a, int64_t lda, const void*
     if (hs == HIPBLAS_STATUS_SUCCESS) hs = api.heuristic(handle, pl.desc, pl.la, pl.lb, pl.lc, pl.ld, pref, 1, pl.res(), &found);
     if (pref) api.pref_destroy(pref);
     if (hs != HIPBLAS_STATUS_SUCCESS || found < 1 || pl.res()->state != HIPBLAS_STATUS_SUCCESS) {
+      api.desc_destroy(pl.desc);
+      for (hipblasLtMatrixLayout_t l : {pl.la, pl.lb, pl.lc, pl.ld}) api.layout_destroy(l);
       g_plans.erase(key);
       return set_error(HSTU_EUNSUPPORTED, "hstu_addmm_residual: hipBLASLt has no algorithm for (%lld, %d, %d) (status %d)", (long long)m, n, k, (int)hs);
     }

@@ -174,6 +174,21 @@ def test_addmm_residual_one_launch_matches_fp64_and_torch(shape, dtype):
     assert torch.equal(_launch.addmm_residual(x, y, w), out)
 
 
+def test_addmm_residual_plan_cache_turns_over():
+    """jagged batches change the row count every call: 600 different problems run through the bounded plan cache (256) and stay right"""
+    from generative_recommenders_amd.ops import _launch
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w = (torch.randn(96, 64, generator=g) / 10).to(torch.bfloat16).cuda()
+    xs = torch.randn(700, 64, generator=g).to(torch.bfloat16).cuda()
+    ys = torch.randn(700, 96, generator=g).to(torch.bfloat16).cuda()
+    for m in list(range(1, 601)) + [5, 300, 600]:
+        out = _launch.addmm_residual(xs[:m], ys[:m], w)
+        if m % 97 == 0 or m <= 3 or m == 600:
+            ref = xs[:m].double() + ys[:m].double() @ w.double()
+            assert float((out.double() - ref).norm() / ref.norm()) < 3e-3, m
+
+
 def test_addmm_op_takes_the_one_launch_path_only_without_autograd():
     from generative_recommenders_amd.ops.mm import addmm
 
