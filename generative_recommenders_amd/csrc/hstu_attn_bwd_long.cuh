@@ -273,6 +273,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void hstu_attn_bwd_dq_kernel(const 
     tile_dma<T, D>(st + C::KT, vbase, v_rs, kv_lo + 32 * t, len, D, wave, 4, lane);
   };
   for (int t = 0; t < C::NS - 1 && t < ntiles; ++t) issue_tile(t, t);
+  // (target rows only and every row of this wave in front of the first target: the plain causal path, as in hstu_attn_fwd_kernel)
+  const bool wave_plain = mc.simple || (HSTU_TARGETS_PLAIN && mc.has_targets && mc.win == 0 && mc.ctx == 0 && r0 + 32 <= min(len, mc.max_id));
 
   for (int t = 0; t < ntiles; ++t) {
     const int slot = t % C::NS;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void hstu_attn_bwd_dq_kernel(const 
     asm volatile("" ::: "memory");
     if (t + C::NS - 1 < ntiles) issue_tile(t + C::NS - 1, (slot + C::NS - 1) % C::NS);
     bool tile_act, tile_full;
-    if (mc.simple) {
+    if (wave_plain) {
       tile_act = r0 < len && j0 <= min(r0 + 31, len - 1);
       tile_full = j0 + 32 <= r0;        // strictly below this wave's first row
     } else {
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void hstu_attn_bwd_dq_kernel(const 
     // mode (wave-uniform): 0 no mask, 4 plain causal (the only partly masked tile is the aligned diagonal one: a lane-constant
     // pattern, put into S itself -- a masked element is -1e30, alpha S hugely negative, exp2 gives +inf, the sigmoid exactly 0 and
     // dS' = dP * 0), 3 targets / window by integer arithmetic, 2 contextual rows: the general predicate by compares
-    const int mode = tile_full ? 0 : (mc.simple ? 4 : ((!CTX || mc.ctx == 0) ? 3 : 2));
+    const int mode = tile_full ? 0 : (wave_plain ? 4 : ((!CTX || mc.ctx == 0) ? 3 : 2));
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
