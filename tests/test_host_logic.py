@@ -18,3 +18,23 @@ def test_length_order_sorts_by_tile_count_and_keeps_batch_order_inside_a_tile_co
     for a, b in zip(order, order[1:]):
         assert tiles[a] > tiles[b] or a < b            # same tile count: batch order
     assert length_order(off) is length_order(off)      # cached per offsets tensor object
+
+
+def test_addmm_residual_is_refused_for_what_the_one_launch_path_cannot_take():
+    """ops/_launch.py::addmm_residual_supported (hstu_addmm_residual, ABI v13): CPU tensors, fp32, a 1-D bias, mismatched shapes and rows that
+    are not 16-byte multiples all stay with torch.addmm -- decided on the host, before anything is launched."""
+    from generative_recommenders_amd.ops import _launch
+
+    x = torch.zeros(8, 16, dtype=torch.bfloat16)
+    y = torch.zeros(8, 32, dtype=torch.bfloat16)
+    w = torch.zeros(32, 16, dtype=torch.bfloat16)
+    assert not _launch.addmm_residual_supported(x, y, w)                          # CPU
+    assert not _launch.addmm_residual_supported(x.float(), y.float(), w.float())  # fp32
+    assert not _launch.addmm_residual_supported(x[0], y, w)                       # 1-D input (a bias)
+    assert not _launch.addmm_residual_supported(x[:, :8], y, w)                   # shape mismatch
+
+
+def test_research_attention_orders_large_batches_only():
+    from generative_recommenders_amd.research.modeling.sequential import hstu as R
+
+    assert R._ORDER_MIN_USERS == 512
