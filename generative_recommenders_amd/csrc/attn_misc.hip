@@ -227,10 +227,10 @@ size_t attn_bwd_workspace_bytes(const HstuAttnBwdParams& bp) {
 // 32768 partial rows of an 8192-user batch: 9 waves on the whole chip.)
 constexpr int kRedChunks = 128;
 
-__global__ void bias_grad_reduce_stage1(const float* partial, int rows, int width, float* chunk_sums) {
+__global__ void bias_grad_reduce_stage1(const float* partial, int rows, int width, int chunks, float* chunk_sums) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= width) return;
-  const int per = (rows + kRedChunks - 1) / kRedChunks;
+  const int per = (rows + chunks - 1) / chunks;
   const int r0 = blockIdx.y * per, r1 = min(r0 + per, rows);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int r = r0;
@@ -247,19 +247,34 @@ __global__ void bias_grad_reduce_stage1(const float* partial, int rows, int widt
 __global__ void bias_grad_reduce_stage2(const float* chunk_sums, int chunks, int width, int npos, float* dpos_w, float* dts_w) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= width) return;
-  float s = 0.f;
-  for (int r = 0; r < chunks; ++r) s += chunk_sums[(int64_t)r * width + c];
+  // (four independent partial sums: the loads of a column are 4 deep in flight instead of one after the other)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < chunks; r += 4) {
+    s0 += chunk_sums[(int64_t)r * width + c];
+    s1 += chunk_sums[(int64_t)(r + 1) * width + c];
+    s2 += chunk_sums[(int64_t)(r + 2) * width + c];
+    s3 += chunk_sums[(int64_t)(r + 3) * width + c];
+  }
+  for (; r < chunks; ++r) s0 += chunk_sums[(int64_t)r * width + c];
+  const float s = (s0 + s1) + (s2 + s3);
   if (c < npos) dpos_w[c] = s;
   else if (dts_w) dts_w[c - npos] = s;
 }
 
 int launch_bias_grad_reduce(const float* partial, int rows, int width, int npos, float* dpos_w, float* dts_w,
                             hipStream_t st) {
-  // the chunk sums live right behind the partial rows (attn_bwd_workspace_bytes reserves kRedChunks extra rows)
+  // the chunk sums live right behind the partial rows (attn_bwd_workspace_bytes reserves kRedChunks extra rows).  Chunks ~ sqrt(rows):
+  // both stages are one thread per column walking its rows one after the other, and with a fixed 128 chunks the second stage was 128
+  // dependent loads for the 256 .. 768 rows of the persistent kernels: 31 us per backward call (12 % of the Amazon-Books research-path
+  // backward: profiles/r06_c3bias_rocprofv3_pmc.md)
+  int chunks = 1;
+  while (chunks * chunks < rows && chunks < kRedChunks) ++chunks;
   float* chunk_sums = const_cast<float*>(partial) + (size_t)rows * width;
-  hipLaunchKernelGGL(bias_grad_reduce_stage1, dim3((width + 63) / 64, kRedChunks), dim3(64), 0, st, partial, rows, width, chunk_sums);
+  hipLaunchKernelGGL(bias_grad_reduce_stage1, dim3((width + 63) / 64, chunks), dim3(64), 0, st, partial, rows, width, chunks, chunk_sums);
   if (int e = check_launch("hstu_attn_bwd(bias gradient reduce 1)")) return e;
-  hipLaunchKernelGGL(bias_grad_reduce_stage2, dim3((width + 63) / 64), dim3(64), 0, st, chunk_sums, kRedChunks, width, npos, dpos_w, dts_w);
+  hipLaunchKernelGGL(bias_grad_reduce_stage2, dim3((width + 63) / 64), dim3(64), 0, st, chunk_sums, chunks, width, npos, dpos_w, dts_w);
   return check_launch("hstu_attn_bwd(bias gradient reduce 2)");
 }
+
 }  // namespace hstu

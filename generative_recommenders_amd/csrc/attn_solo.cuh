@@ -40,6 +40,8 @@ static int launch_bwd_solo(const HstuAttnBwdParams& bp, hipStream_t st) {
     hipLaunchKernelGGL((hstu_attn_bwd_solo_kernel<T, 2>), dim3(solo_grid(total, 2)), dim3(kSoloThreads), smem2, st, bp, 0, kSoloMaxLen);
     return check_launch("hstu_attn_bwd(solo)");
   }
+  // (the two launches one after the other: putting the long class on a side stream of the device -- fork / join by events -- measured
+  // SLOWER, 69 -> 83 us on the Amazon-Books batch: profiles/r06_ab_solo_length_classes.txt)
   if (bp.fwd.max_seq_len > 32) {
     hipLaunchKernelGGL((hstu_attn_bwd_solo_kernel<T, 2>), dim3(solo_grid(total, 2)), dim3(kSoloThreads), smem2, st, bp, 32, kSoloMaxLen);
     if (int rc = check_launch("hstu_attn_bwd(solo)")) return rc;
@@ -113,10 +115,11 @@ static int launch_bwd_solo_bias(const HstuAttnBwdParams& bp, hipStream_t st) {
   int row0 = 0;
   for (int i = 0; i < nl; ++i) {
     const Launch& l = ls[i];
+    hipStream_t s_i = st;
     if (l.tpt == 1)
-      hipLaunchKernelGGL((hstu_attn_bwd_solo_bias_kernel<T, 1>), dim3(l.grid), dim3(kSoloThreads), l.smem, st, bp, partial, l.ts_copies, l.hist, tables, l.len_lo, l.len_hi, row0);
+      hipLaunchKernelGGL((hstu_attn_bwd_solo_bias_kernel<T, 1>), dim3(l.grid), dim3(kSoloThreads), l.smem, s_i, bp, partial, l.ts_copies, l.hist, tables, l.len_lo, l.len_hi, row0);
     else
-      hipLaunchKernelGGL((hstu_attn_bwd_solo_bias_kernel<T, 2>), dim3(l.grid), dim3(kSoloThreads), l.smem, st, bp, partial, l.ts_copies, l.hist, tables, l.len_lo, l.len_hi, row0);
+      hipLaunchKernelGGL((hstu_attn_bwd_solo_bias_kernel<T, 2>), dim3(l.grid), dim3(kSoloThreads), l.smem, s_i, bp, partial, l.ts_copies, l.hist, tables, l.len_lo, l.len_hi, row0);
     if (int rc = check_launch("hstu_attn_bwd(solo, bias)")) return rc;
     row0 += l.grid;
   }

@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
       kargw_t kl = kargs;
       asm volatile("" : "+s"(kl));
       const HstuAttnBwdParams bp = reload_bwd_params(kl);
-      bx.bc = stage_bias_tables(bp.fwd, cur.b, tables, tid, kBwdThreads);
+      bx.bc = stage_bias_tables(bp.fwd, cur.b, tables, tid, kBwdThreads, /*user_only=*/u != (int)blockIdx.x);   // (the weight tables do not depend on the user: staged with the workgroup's first one)
     }
     __syncthreads();
     bx.bc.finish(kBwdWaves);
