@@ -145,4 +145,6 @@ def test_scalar_registers_parked_in_vector_lanes_stay_bounded():
     bias = [v for k, v in census.items() if "fold_bias_kernelIDF16bLi64E" in k]
     assert len(fold) == 1 and len(bias) == 1, census
     assert sum(fold[0]) <= 500, fold         # 458 at the commit that introduced the test
-    assert sum(bias[0]) <= 620, bias         # 574
+    # (574 at the commit that introduced the test; 636 since the kernel takes its users from a counter and stages the weight tables once per
+    # workgroup -- three more wave-uniform values across the user loop -- which measured 16 % FASTER on the ML-20M shape: DESIGN 4.2e)
+    assert sum(bias[0]) <= 680, bias
