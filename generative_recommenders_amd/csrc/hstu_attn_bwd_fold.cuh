@@ -1004,8 +1004,16 @@ __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
   // workgroup had drawn the longest users: ML-20M lengths (uniform in 1 .. 211), 8192 users: 2.78 ms, the SAME batch with its users
   // sorted by length 2.38 (tools/c2_length_order_probe.py).
   volatile int* const slot = (volatile int*)(bx.hpos + 2 * max_seq_len - 1);
+  // (the ticket is drawn one user AHEAD: thread 0 publishes the one it drew during the previous user and draws the next right away -- the
+  // atomic's round trip passes under a whole user instead of in front of the barrier every wave waits at: C2 backward -0.6 %.  Requesting
+  // the next user's timestamps ahead as well -- registers across the head loop -- gave that back: not adopted)
+  int ticket = 0;
+  if (tid == 0) ticket = (int)gridDim.x + atomicAdd(next_user, 1);
   for (int u = blockIdx.x; u < batch;) {
-    if (tid == 0) *slot = (int)gridDim.x + atomicAdd(next_user, 1);
+    if (tid == 0) {
+      *slot = ticket;
+      ticket = (int)gridDim.x + atomicAdd(next_user, 1);
+    }
     __syncthreads();                       // the previous user's pairs have read their last table entry
     {
       kargw_t kl = kargs;
